@@ -1,0 +1,169 @@
+"""Pins the CPU restatements (oracle/) against the golden fixtures made from the imported reference
+(oracle/make_golden.py).  Bit-exact: observations (f32), rewards, load, queue, sim_time, metrics (f64)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, philox_ref
+from oracle import edge_env_oracle as eo
+from tests.golden_util import METRIC_KEYS, config_for, env_fixtures, load_env_fixture
+
+FIXTURES = env_fixtures()
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) >= 6
+
+
+def _rank_from_order(order, n):
+    r = np.full(n, -1, np.int8)
+    for i, a in enumerate(order):
+        r[a] = i
+    return r
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=lambda p: p.split("env_")[-1][:-4])
+def test_python_restatement_on_tape(path):
+    g = load_env_fixture(path)
+    cfg = config_for(g, eo.default_config())
+    n, T = cfg["n_nodes"], cfg["episode_length"]
+    tape_out = eo.empty_tape(T + 1, n, a_slots=g["tape"]["task_wl"].shape[1])
+    env = eo.EdgeEnvOracle(cfg, eo.TapeDraws(g["tape"]), tape_out=tape_out)
+    env.explore_counter = int(g["explore_counter0"])
+    obs, order = env.reset()
+    assert np.array_equal(obs, g["obs"][0])
+    assert np.array_equal(_rank_from_order(order, n), g["rank"][0])
+    for t in range(T):
+        out = env.step(g["placements"][t], g["resources"][t])
+        assert np.array_equal(out.obs, g["obs"][t + 1]), t
+        assert np.array_equal(_rank_from_order(out.order, n), g["rank"][t + 1]), t
+        assert out.reward == g["reward"][t] and out.reward_emitted == g["reward_emitted"][t], t
+        assert out.done == g["done"][t]
+        assert np.array_equal(env.load, g["load"][t + 1]) and np.array_equal(env.queue, g["queue"][t + 1])
+        assert env.sim_time == g["sim_time"][t + 1]
+        k = len(out.latencies)
+        assert np.array_equal(np.array(out.latencies), g["step_lat"][t, :k]) and np.isnan(g["step_lat"][t, k:]).all()
+        assert env.ep_viol == g["n_viol"][t + 1] and len(env.ep_lat) == g["n_tasks"][t + 1]
+    m = env.episode_metrics()
+    assert [m[k] for k in METRIC_KEYS] == list(g["metrics"])
+    # the run re-emits exactly the tape it consumed (same number of draws per step)
+    assert np.array_equal(tape_out["n_draws"], g["tape"]["n_draws"])
+    assert np.array_equal(tape_out["n_act"], g["tape"]["n_act"])
+
+
+@pytest.mark.parametrize("path", [p for p in FIXTURES if "seed0" in p or "seed2" in p],
+                         ids=lambda p: p.split("env_")[-1][:-4])
+def test_python_restatement_from_seed(path):
+    """With numpy's legacy RandomState the restatement reproduces the reference from the seed alone."""
+    g = load_env_fixture(path)
+    cfg = config_for(g, eo.default_config())
+    env = eo.EdgeEnvOracle(cfg, eo.LegacyDraws(0))
+    env.explore_counter = int(g["explore_counter0"])
+    obs, _ = env.reset(seed=int(g["seed"]))
+    assert np.array_equal(obs, g["obs"][0])
+    total = 0.0
+    for t in range(cfg["episode_length"]):
+        out = env.step(g["placements"][t], g["resources"][t])
+        assert np.array_equal(out.obs, g["obs"][t + 1]), t
+        assert out.reward == g["reward"][t]
+        total += out.reward if out.reward_emitted else 0
+    if "seed0" in path:
+        assert total == -1421.8129109444526   # SURVEY.md section 8c golden
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=lambda p: p.split("env_")[-1][:-4])
+def test_c_restatement_on_tape(path):
+    g = load_env_fixture(path)
+    cfg = config_for(g, eo.default_config())
+    n, T = cfg["n_nodes"], cfg["episode_length"]
+    env = c_oracle.COracleEnv(cfg, 1)
+    env.set_explore(cfg["disable_env_exploration"], int(g["explore_counter0"]))
+    tp = c_oracle.TapeStep(c_oracle.tape_step_from_golden([g["tape"]], 0), 1, n)
+    obs, mask, rank = env.reset(tp)
+    assert np.array_equal(obs[0], g["obs"][0]) and np.array_equal(rank[0], g["rank"][0])
+    for t in range(T):
+        tp = c_oracle.TapeStep(c_oracle.tape_step_from_golden([g["tape"]], t + 1), 1, n)
+        obs, rew, emitted, done = env.step(g["placements"][t][None], g["resources"][t][None], tp)
+        assert np.array_equal(obs[0], g["obs"][t + 1]), t
+        assert np.array_equal(env.rank[0], g["rank"][t + 1]), t
+        assert rew[0] == g["reward"][t] and bool(emitted[0]) == g["reward_emitted"][t], t
+        assert bool(done[0]) == g["done"][t]
+        assert env.n_draws[0] == g["tape"]["n_draws"][t + 1], t
+        st = env.state()
+        assert np.array_equal(st["load"][0], g["load"][t + 1]) and np.array_equal(st["queue"][0], g["queue"][t + 1])
+        assert st["sim_time"][0] == g["sim_time"][t + 1]
+        k = int(np.sum(~np.isnan(env.step_lat[0])))
+        assert np.array_equal(env.step_lat[0, :k], g["step_lat"][t, :k]) and np.isnan(g["step_lat"][t, k:]).all()
+    assert np.array_equal(env.metrics()[0], g["metrics"])
+    assert list(st["counts"][0]) == [g["n_tasks"][-1], g["n_viol"][-1], g["n_completed"][-1]]
+
+
+@pytest.mark.parametrize("explore,mode", [(False, "cyclic"), (True, "cyclic"), (False, "random")])
+def test_c_restatement_matches_python_on_philox_stream(explore, mode):
+    cfg = eo.default_config()
+    cfg.update(episode_length=150, disable_env_exploration=not explore, task_arrival_mode=mode)
+    cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 100}
+    B, n, T, seed, off = 5, 10, 150, 0x1234567890ABCDEF, 77
+    cenv = c_oracle.COracleEnv(cfg, B, seed=seed, env_offset=off)
+    cenv.set_explore(not explore, 0)
+    cenv.next_episode()          # episode index 1 on both sides
+    pys = [eo.EdgeEnvOracle(cfg, eo.PhiloxDraws(seed, off + b, episode=1)) for b in range(B)]
+    obs, mask, rank = cenv.reset()
+    for b, p in enumerate(pys):
+        o, order = p.reset()
+        assert np.array_equal(o, obs[b]) and np.array_equal(_rank_from_order(order, n), rank[b])
+    rs = np.random.RandomState(5)
+    for t in range(T):
+        pl = rs.randint(0, n, size=(B, n)).astype(np.int32)
+        rsrc = rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32)
+        obs, rew, emitted, done = cenv.step(pl, rsrc)
+        st = cenv.state()
+        for b, p in enumerate(pys):
+            out = p.step(pl[b], rsrc[b])
+            assert np.array_equal(out.obs, obs[b]), (t, b)
+            assert out.reward == rew[b] and out.reward_emitted == bool(emitted[b]) and out.done == bool(done[b])
+            assert np.array_equal(p.load, st["load"][b]) and np.array_equal(p.queue, st["queue"][b])
+            assert p.sim_time == st["sim_time"][b]
+    cm = cenv.metrics()
+    for b, p in enumerate(pys):
+        m = p.episode_metrics()
+        assert [m[k] for k in METRIC_KEYS] == list(cm[b])
+    assert cenv.explore_counter == (T if explore else 0)
+
+
+def test_numpy_summation_order_and_percentile():
+    L = c_oracle.lib()
+    rs = np.random.RandomState(0)
+    for n in list(range(0, 20)) + [127, 128, 129, 200, 257, 1000, 4099]:
+        a = rs.uniform(-3, 50, size=n) * 10.0 ** rs.randint(-3, 4, size=n)
+        got = 0.0 + L.np_pairwise_sum(a.ctypes.data, n)
+        assert got == float(np.sum(a)), n
+        if n:
+            assert L.np_percentile_linear(a.ctypes.data, n, 99.0) == float(np.percentile(a, 99)), n
+
+
+def test_philox_known_answers_and_det_math():
+    L = c_oracle.lib()
+    kat = [((0, 0, 0, 0), 0, (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, 0xFFFFFFFFFFFFFFFF, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), 0x299F31D0A4093822,
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    out = np.zeros(4, np.uint32)
+    for ctr, seed, want in kat:
+        assert philox_ref.philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)) == want
+        L.eo_philox(*ctr, seed, out.ctypes.data)
+        assert tuple(int(x) for x in out) == want
+    rs = np.random.RandomState(1)
+    for x in rs.uniform(0, 1, 2000):
+        assert L.eo_det_sin2pi(x) == philox_ref.det_sin2pi(x)
+        assert abs(L.eo_det_sin2pi(x) - np.sin(2 * np.pi * x)) < 1e-14
+        assert L.eo_det_exp(-30 * x) == philox_ref.det_exp(-30 * x)
+        assert abs(L.eo_det_exp(-30 * x) / np.exp(-30 * x) - 1) < 1e-13
+        u = 1.0 - x
+        assert L.eo_det_log(u) == philox_ref.det_log(u)
+        assert abs(L.eo_det_log(u) - np.log(u)) < 1e-14 * max(1.0, abs(np.log(u)))
+
+
+def test_gae_known_answer():
+    # known answer obtained from the imported reference compute_gae
+    adv, ret = c_oracle.gae([1, 2, 3], [0.5, 0.4, 0.3], [0, 0, 1], 0.0, 0.99, 0.95)
+    assert list(adv) == [5.068387175000001, 4.436350000000001, 2.7]
