@@ -1,0 +1,81 @@
+"""ctypes binding of libedgemarl.so (C ABI: include/edgemarl.h).  Fails loudly when the HIP library
+has not been built: there is no CPU path behind this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# torch bundles its own HIP runtime (libamdhip64.so.7).  It must be the first one loaded in the
+# process so that libedgemarl.so binds to the same runtime instance (same soname) and shares torch's
+# device context, streams and allocations; loading /opt/rocm's copy first gives two runtimes.
+import torch  # noqa: F401
+
+from .config import EmConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
+ABI_VERSION = 1
+
+
+class EmTape(C.Structure):
+    _fields_ = [
+        ("explore_u", C.c_void_p), ("explore_res", C.c_void_p), ("bw_u", C.c_void_p), ("net_lat", C.c_void_p),
+        ("explore_tgt", C.c_void_p),
+        ("rate_u", C.c_void_p), ("dt_raw", C.c_void_p),
+        ("n_arrivals", C.c_void_p),
+        ("task_workload", C.c_void_p), ("task_data", C.c_void_p), ("task_deadline_offset", C.c_void_p),
+        ("task_decider", C.c_void_p),
+        ("arrival_slots", C.c_int32),
+    ]
+
+
+class EmStepOut(C.Structure):
+    _fields_ = [
+        ("obs", C.c_void_p), ("active", C.c_void_p), ("rank", C.c_void_p), ("reward", C.c_void_p),
+        ("emitted", C.c_void_p), ("done", C.c_void_p), ("step_latency", C.c_void_p), ("n_draws", C.c_void_p),
+        ("reward_seen", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP kernels first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C marl_amd/csrc).  marl_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.em_abi_version.restype = C.c_int
+    if L.em_abi_version() != ABI_VERSION:
+        raise RuntimeError("libedgemarl.so ABI version mismatch; rebuild marl_amd/csrc")
+    L.em_last_error.restype = C.c_char_p
+    vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int
+    L.em_create.argtypes = [C.POINTER(EmConfig), i64, i32, u64, u64, i64, C.POINTER(vp)]
+    L.em_destroy.argtypes = [vp]
+    L.em_reset.argtypes = [vp, C.POINTER(EmTape), i32, u64, C.POINTER(EmStepOut), vp]
+    L.em_step.argtypes = [vp, vp, vp, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
+    L.em_episode_metrics.argtypes = [vp, vp, vp]
+    L.em_set_exploration.argtypes = [vp, i32, i64]
+    L.em_get_exploration_counter.argtypes = [vp]
+    L.em_get_exploration_counter.restype = i64
+    L.em_get_state.argtypes = [vp] + [vp] * 7
+    L.em_record_bytes.argtypes = [vp]
+    L.em_record_bytes.restype = i64
+    L.em_n_envs.argtypes = [vp]
+    L.em_n_envs.restype = i64
+    L.em_set_lanes_per_env.argtypes = [vp, i32]
+    for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
+                 "em_get_state", "em_set_lanes_per_env"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "libedgemarl"):
+    if rc != 0:
+        msg = lib().em_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,88 @@
+"""Environment configuration: the reference's ENV_CONFIG keys (MRRL.PY:70-110), unchanged."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+EM_MAX_NODES = 64
+
+ENV_CONFIG = {
+    "n_nodes": 10,
+    "task_arrival_rate": 10,
+    "task_arrival_rate_range": (5, 15),
+    "task_arrival_mode": "cyclic",
+    "task_arrival_cycle_seconds": 20.0,
+    "episode_length": 1000,
+    "node_cpu_capacity": np.array([1.0, 1.2, 1.4, 1.6, 1.8, 2.0, 2.2, 2.4, 2.6, 3.0]) * 1e9,
+    "task_workload_range": (1.0, 10.0),
+    "task_data_range": (0.5, 5.0),
+    "task_deadline_range": (0.05, 0.5),
+    "network_bw_range": (10, 100),
+    "network_latency_range": (0.002, 0.01),
+    "reward_weights": {"alpha": 0.5, "beta": 0.3, "gamma": 0.2},
+    "min_time_step": 0.02,
+    "max_time_step": 0.2,
+    "initial_observation_window": 0.1,
+    "exploration_schedule": {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 1_000_000},
+    "disable_env_exploration": False,
+}
+
+
+class EmConfig(C.Structure):
+    """ctypes image of ``em_config`` (include/edgemarl.h)."""
+
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("episode_length", C.c_int32), ("arrival_mode", C.c_int32),
+        ("disable_env_exploration", C.c_int32),
+        ("node_cpu_capacity", C.c_double * EM_MAX_NODES),
+        ("arrival_rate_lo", C.c_double), ("arrival_rate_hi", C.c_double), ("arrival_cycle_seconds", C.c_double),
+        ("workload_lo", C.c_double), ("workload_hi", C.c_double),
+        ("data_lo", C.c_double), ("data_hi", C.c_double),
+        ("deadline_lo", C.c_double), ("deadline_hi", C.c_double),
+        ("bw_lo", C.c_double), ("bw_hi", C.c_double),
+        ("net_latency_lo", C.c_double), ("net_latency_hi", C.c_double),
+        ("w_latency", C.c_double), ("w_energy", C.c_double), ("w_violation", C.c_double),
+        ("min_time_step", C.c_double), ("max_time_step", C.c_double), ("initial_observation_window", C.c_double),
+        ("initial_epsilon", C.c_double), ("final_epsilon", C.c_double),
+        ("decay_steps", C.c_int64),
+    ]
+
+
+_ARRIVAL_MODES = {"cyclic": 1, "random": 2}
+
+
+def make_em_config(config: dict) -> EmConfig:
+    """Same defaults as EdgeSimGym.__init__ (MRRL.PY:128-148)."""
+    c = EmConfig()
+    n = int(config["n_nodes"])
+    if not 1 <= n <= EM_MAX_NODES:
+        raise ValueError(f"n_nodes must be in 1..{EM_MAX_NODES}")
+    c.n_nodes = n
+    c.episode_length = int(config["episode_length"])
+    rate = config.get("task_arrival_rate", 10)
+    lo, hi = config.get("task_arrival_rate_range", (rate, rate))
+    c.arrival_rate_lo, c.arrival_rate_hi = float(lo), float(hi)
+    c.arrival_mode = _ARRIVAL_MODES.get(config.get("task_arrival_mode", "cyclic"), 0)
+    c.arrival_cycle_seconds = float(config.get("task_arrival_cycle_seconds", 20.0))
+    c.disable_env_exploration = int(bool(config.get("disable_env_exploration", False)))
+    caps = np.asarray(config["node_cpu_capacity"], dtype=np.float64).reshape(-1)
+    if caps.size < n:
+        raise ValueError("node_cpu_capacity shorter than n_nodes")
+    for i in range(n):
+        c.node_cpu_capacity[i] = float(caps[i])
+    c.workload_lo, c.workload_hi = map(float, config["task_workload_range"])
+    c.data_lo, c.data_hi = map(float, config["task_data_range"])
+    c.deadline_lo, c.deadline_hi = map(float, config["task_deadline_range"])
+    c.bw_lo, c.bw_hi = map(float, config["network_bw_range"])
+    c.net_latency_lo, c.net_latency_hi = map(float, config["network_latency_range"])
+    w = config["reward_weights"]
+    c.w_latency, c.w_energy, c.w_violation = float(w["alpha"]), float(w["beta"]), float(w["gamma"])
+    c.min_time_step = float(config.get("min_time_step", 0.02))
+    c.max_time_step = float(config.get("max_time_step", 0.2))
+    c.initial_observation_window = float(config.get("initial_observation_window", 0.1))
+    sch = config.get("exploration_schedule", {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 1_000_000})
+    c.initial_epsilon = float(sch.get("initial_epsilon", 1.0))
+    c.final_epsilon = float(sch.get("final_epsilon", 0.05))
+    c.decay_steps = int(sch.get("decay_steps", 1_000_000))
+    return c

@@ -1,0 +1,189 @@
+"""Batched EdgeSimGym on MI355X: the reference's ``reset()/step(actions)`` API (MRRL.PY:188,386) with a
+leading batch-of-environments dimension.  All arithmetic happens in the HIP kernels of
+``csrc/edge_env.hip``; torch only owns the device buffers and the stream."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ENV_CONFIG, make_em_config
+
+METRIC_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "violation_rate", "throughput_tps",
+               "load_balance_jain")
+
+_TAPE_F64 = ("explore_u", "explore_res", "bw_u", "net_lat", "rate_u", "dt_raw", "task_workload", "task_data",
+             "task_deadline_offset")
+_TAPE_I32 = ("explore_tgt", "n_arrivals", "task_decider")
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class DeviceTape:
+    """One step of pre-drawn random numbers on the device (``em_tape``).  ``arrays`` maps the field
+    names of ``em_tape`` to array-likes with leading dimension n_envs; missing optional fields stay NULL."""
+
+    def __init__(self, arrays: dict, device):
+        self.tensors = {}
+        st = _lib.EmTape()
+        for k, v in arrays.items():
+            if k in _TAPE_F64:
+                t = torch.as_tensor(np.ascontiguousarray(v, np.float64)).to(device)
+            elif k in _TAPE_I32:
+                t = torch.as_tensor(np.ascontiguousarray(v, np.int32)).to(device)
+            else:
+                raise KeyError(f"unknown tape field {k}")
+            self.tensors[k] = t
+            setattr(st, k, t.data_ptr())
+        st.arrival_slots = int(self.tensors["task_workload"].shape[-1]) if "task_workload" in self.tensors else 0
+        self.struct = st
+
+
+class BatchedEdgeSimGym:
+    """``n_envs`` independent EdgeSimGym instances stepped by one kernel launch.
+
+    reset(seed=None) -> (obs[B,N,N+4] f32, active[B] int64 bitmask)
+    step(placement[B,N] i32, resource[B,N] f32) -> (obs, reward[B] f64, done[B] u8, truncated[B] u8, info)
+
+    ``reward`` already applies the reference's consumer rule (mappo_trainer.py:209-212): it is 0 when
+    the new observation set is empty; ``info["reward_raw"]``/``info["emitted"]`` hold the two parts.
+    Returned tensors are views of buffers owned by the environment and are overwritten by the next call.
+    """
+
+    def __init__(self, config=None, n_envs: int = 1, device="cuda:0", seed: int = 0, env_offset: int = 0,
+                 latency_log_capacity: int | None = None):
+        self.config = dict(ENV_CONFIG if config is None else config)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedEdgeSimGym runs on an MI355X (device='cuda:N'); there is no CPU path")
+        self.n_envs = int(n_envs)
+        self.n_nodes = int(self.config["n_nodes"])
+        self.episode_len = int(self.config["episode_length"])
+        self.cpu_caps = np.asarray(self.config["node_cpu_capacity"], np.float64)
+        self._cfg = make_em_config(self.config)
+        if latency_log_capacity is None:   # exact p99 needs every latency of the episode (MRRL.PY:476-479)
+            latency_log_capacity = self.episode_len * self.n_nodes if self.n_envs <= 1024 else 0
+        self.latency_log_capacity = int(latency_log_capacity)
+        self._L = _lib.lib()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._h = C.c_void_p()
+        with torch.cuda.device(dev_index):
+            _lib.check(self._L.em_create(C.byref(self._cfg), self.n_envs, dev_index, int(seed) & (2**64 - 1),
+                                         int(env_offset), self.latency_log_capacity, C.byref(self._h)), "em_create")
+        B, n = self.n_envs, self.n_nodes
+        d = self.device
+        self.obs = torch.zeros((B, n, n + 4), dtype=torch.float32, device=d)
+        self.active = torch.zeros(B, dtype=torch.int64, device=d)
+        self.rank = torch.full((B, n), -1, dtype=torch.int8, device=d)
+        self.reward_raw = torch.zeros(B, dtype=torch.float64, device=d)
+        self.reward = torch.zeros(B, dtype=torch.float64, device=d)
+        self.emitted = torch.zeros(B, dtype=torch.uint8, device=d)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=d)
+        self.truncated = torch.zeros(B, dtype=torch.uint8, device=d)
+        self.step_latency = None
+        self.n_draws = None
+        self._out = _lib.EmStepOut()
+        self._bind_outputs()
+        self._disable_env_exploration = bool(self.config.get("disable_env_exploration", False))
+
+    # ------------------------------------------------------------------------------------------
+    def _bind_outputs(self):
+        o = self._out
+        o.obs, o.active, o.rank = self.obs.data_ptr(), self.active.data_ptr(), self.rank.data_ptr()
+        o.reward, o.emitted, o.done = self.reward_raw.data_ptr(), self.emitted.data_ptr(), self.done.data_ptr()
+        o.step_latency = self.step_latency.data_ptr() if self.step_latency is not None else None
+        o.n_draws = self.n_draws.data_ptr() if self.n_draws is not None else None
+        o.reward_seen = self.reward.data_ptr()
+
+    def enable_debug_outputs(self):
+        """Also produce per-slot latencies and draw counts each step (parity tests)."""
+        B, n = self.n_envs, self.n_nodes
+        self.step_latency = torch.zeros((B, n), dtype=torch.float64, device=self.device)
+        self.n_draws = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._bind_outputs()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.em_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- exploration switch/counter (MRRL.PY:122,179; mappo_trainer.py:336-346) ------------------
+    @property
+    def disable_env_exploration(self) -> bool:
+        return self._disable_env_exploration
+
+    @disable_env_exploration.setter
+    def disable_env_exploration(self, v: bool):
+        self._disable_env_exploration = bool(v)
+        _lib.check(self._L.em_set_exploration(self._h, int(bool(v)), self.global_step_counter))
+
+    @property
+    def global_step_counter(self) -> int:
+        return int(self._L.em_get_exploration_counter(self._h))
+
+    @global_step_counter.setter
+    def global_step_counter(self, v: int):
+        _lib.check(self._L.em_set_exploration(self._h, int(self._disable_env_exploration), int(v)))
+
+    def set_lanes_per_env(self, lanes: int):
+        _lib.check(self._L.em_set_lanes_per_env(self._h, int(lanes)))
+
+    @property
+    def record_bytes(self) -> int:
+        return int(self._L.em_record_bytes(self._h))
+
+    # -- API ---------------------------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None, tape: DeviceTape | None = None):
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_reset(self._h, C.byref(tape.struct) if tape is not None else None,
+                                        0 if seed is None else 1, 0 if seed is None else int(seed) & (2**64 - 1),
+                                        C.byref(self._out), _stream_ptr(self.device)), "em_reset")
+        return self.obs, self.active
+
+    def step(self, placement: torch.Tensor, resource: torch.Tensor, tape: DeviceTape | None = None):
+        B, n = self.n_envs, self.n_nodes
+        if placement.dtype != torch.int32 or resource.dtype != torch.float32:
+            raise TypeError("placement must be int32 and resource float32")
+        if placement.shape != (B, n) or resource.shape[:2] != (B, n) or resource.numel() != B * n:
+            raise ValueError(f"placement/resource must have shape [{B}, {n}]")
+        if placement.device != self.device or resource.device != self.device:
+            raise ValueError("actions must live on the environment's device")
+        if not (placement.is_contiguous() and resource.is_contiguous()):
+            raise ValueError("actions must be contiguous")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_step(self._h, placement.data_ptr(), resource.data_ptr(),
+                                       C.byref(tape.struct) if tape is not None else None, C.byref(self._out),
+                                       _stream_ptr(self.device)), "em_step")
+        info = {"reward_raw": self.reward_raw, "emitted": self.emitted, "rank": self.rank, "active": self.active}
+        return self.obs, self.reward, self.done, self.truncated, info
+
+    def episode_metrics(self) -> torch.Tensor:
+        out = torch.zeros((self.n_envs, 6), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_episode_metrics(self._h, out.data_ptr(), _stream_ptr(self.device)), "em_episode_metrics")
+        return out
+
+    def get_state(self) -> dict:
+        B, n = self.n_envs, self.n_nodes
+        st = {"load": np.zeros((B, n)), "queue": np.zeros((B, n)), "sim_time": np.zeros(B), "elapsed": np.zeros(B),
+              "step": np.zeros(B, np.int32), "counts": np.zeros((B, 3), np.int64)}
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_get_state(self._h, p(st["load"]), p(st["queue"]), p(st["sim_time"]), p(st["elapsed"]),
+                                            p(st["step"]), p(st["counts"]), _stream_ptr(self.device)), "em_get_state")
+        return st
+
+    @property
+    def nodes_load(self) -> np.ndarray:
+        """[B, N] float64 host copy (the reference attribute read by the greedy baseline, MRRL.PY:808)."""
+        return self.get_state()["load"]

@@ -1,0 +1,57 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU and exports every symbol that
+include/edgemarl.h declares (no compute call is made here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "edgemarl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(em_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    for must in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_last_error"):
+        assert must in names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from marl_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail("libedgemarl.so not built: run __graft_entry__.build()")
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(L, n)]
+    assert not missing, missing
+    assert _lib.lib().em_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    """The ctypes images must have the C layout (double alignment makes these sizes exact)."""
+    from marl_amd import _lib
+    from marl_amd.config import EmConfig
+    assert ctypes.sizeof(EmConfig) == 16 + 64 * 8 + 21 * 8 + 8 == 704
+    assert ctypes.sizeof(_lib.EmTape) == 12 * 8 + 8
+    assert ctypes.sizeof(_lib.EmStepOut) == 9 * 8
+
+
+def test_no_cpu_fallback():
+    """The product refuses to run without a GPU device instead of silently computing on the CPU."""
+    from marl_amd.env import BatchedEdgeSimGym
+    with pytest.raises(RuntimeError):
+        BatchedEdgeSimGym(n_envs=2, device="cpu")
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "marl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert not re.search(r'#include\s*[<"][^>"]*oracle', src), f
+                assert "libedge_oracle" not in src and "dlopen" not in src, f

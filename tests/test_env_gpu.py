@@ -1,0 +1,192 @@
+"""GPU parity of the HIP EdgeSimGym kernels (through the C ABI) against
+ (1) the golden tapes and outputs recorded from the imported reference (bit-exact), and
+ (2) the C restatement on the Philox stream at BASELINE.json's 4096-environment size (bit-exact),
+ (3) size-independent properties at 65,536 environments.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import edge_env_oracle as eo
+from tests.golden_util import config_for, env_fixtures, load_env_fixture
+
+pytestmark = pytest.mark.gpu
+
+TAPE_MAP = {"explore_u": "explore_u", "explore_res": "explore_res", "bw_u": "bw_u", "lat": "net_lat",
+            "explore_tgt": "explore_tgt", "rate_u": "rate_u", "dt_raw": "dt_raw", "n_arr": "n_arrivals",
+            "task_wl": "task_workload", "task_data": "task_data", "task_ddl_off": "task_deadline_offset",
+            "task_decider": "task_decider"}
+
+
+def _device_tape(tapes, s, device):
+    from marl_amd.env import DeviceTape
+    return DeviceTape({TAPE_MAP[k]: np.stack([t[k][s] for t in tapes]) for k in TAPE_MAP}, device)
+
+
+def _mask_from_rank(rank):
+    return sum((1 << i) for i, r in enumerate(rank) if r >= 0)
+
+
+@pytest.mark.parametrize("lanes", [0, 32, 64])
+@pytest.mark.parametrize("path", env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
+def test_tape_parity_with_reference_goldens(path, lanes):
+    from marl_amd.env import BatchedEdgeSimGym
+    g = load_env_fixture(path)
+    if lanes and "seed0" in path:
+        pytest.skip("long fixture runs once")
+    cfg = config_for(g, eo.default_config())
+    n, T = cfg["n_nodes"], cfg["episode_length"]
+    B = 3   # the same tape in three environments: exercises the multi-env-per-wave packing and the tail
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0")
+    env.set_lanes_per_env(lanes)
+    env.enable_debug_outputs()
+    env.global_step_counter = int(g["explore_counter0"])
+    tapes = [g["tape"]] * B
+    obs, active = env.reset(tape=_device_tape(tapes, 0, env.device))
+    assert np.array_equal(obs.cpu().numpy(), np.stack([g["obs"][0]] * B))
+    assert list(active.cpu().numpy()) == [_mask_from_rank(g["rank"][0])] * B
+    assert np.array_equal(env.rank.cpu().numpy(), np.stack([g["rank"][0]] * B))
+    pl_all = torch.as_tensor(g["placements"]).to(env.device)
+    rs_all = torch.as_tensor(g["resources"]).to(env.device)
+    for t in range(T):
+        pl = pl_all[t].unsqueeze(0).expand(B, n).contiguous()
+        rs = rs_all[t].unsqueeze(0).expand(B, n).contiguous()
+        obs, rew, done, trunc, info = env.step(pl, rs, tape=_device_tape(tapes, t + 1, env.device))
+        o = obs.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(o[b], g["obs"][t + 1]), (t, b)
+        assert np.array_equal(env.rank.cpu().numpy(), np.stack([g["rank"][t + 1]] * B)), t
+        assert list(info["reward_raw"].cpu().numpy()) == [g["reward"][t]] * B, t
+        assert list(info["emitted"].cpu().numpy()) == [int(g["reward_emitted"][t])] * B
+        assert list(rew.cpu().numpy()) == [g["reward"][t] if g["reward_emitted"][t] else 0.0] * B
+        assert list(done.cpu().numpy()) == [int(g["done"][t])] * B
+        assert list(env.n_draws.cpu().numpy()) == [g["tape"]["n_draws"][t + 1]] * B, t
+        sl = env.step_latency.cpu().numpy()
+        assert np.array_equal(sl[0], g["step_lat"][t], equal_nan=True) and np.array_equal(sl[0], sl[B - 1], equal_nan=True)
+        if t % 25 == 0 or t == T - 1:
+            st = env.get_state()
+            for b in range(B):
+                assert np.array_equal(st["load"][b], g["load"][t + 1]) and np.array_equal(st["queue"][b], g["queue"][t + 1])
+                assert st["sim_time"][b] == g["sim_time"][t + 1]
+                assert list(st["counts"][b]) == [g["n_tasks"][t + 1], g["n_viol"][t + 1], g["n_completed"][t + 1]]
+    m = env.episode_metrics().cpu().numpy()
+    # p99 (sorted log), violation rate, throughput: exact; the two means use a running sum instead of numpy's
+    # pairwise order and Jain's index is computed from elapsed time: 1e-12 relative.
+    for b in range(B):
+        assert m[b, 1] == g["metrics"][1] and m[b, 3] == g["metrics"][3] and m[b, 4] == g["metrics"][4]
+        np.testing.assert_allclose(m[b], g["metrics"], rtol=1e-12, atol=0)
+    assert env.global_step_counter == int(g["explore_counter0"]) + (0 if cfg["disable_env_exploration"] else T)
+
+
+@pytest.mark.parametrize("explore,mode,B", [(True, "cyclic", 4096 + 3), (False, "random", 259)])
+def test_philox_parity_with_c_restatement(explore, mode, B):
+    """configs[1] size: 4096 (+3 to hit the partial wavefront) environments, random actions."""
+    from marl_amd.env import BatchedEdgeSimGym
+    T = 250
+    cfg = eo.default_config()
+    cfg.update(episode_length=T, disable_env_exploration=not explore, task_arrival_mode=mode)
+    cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 120}
+    seed, off, n = 0xC0FFEE1234, 1000, 10
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=seed, env_offset=off, latency_log_capacity=T * n)
+    env.enable_debug_outputs()
+    ref = c_oracle.COracleEnv(cfg, B, seed=seed, env_offset=off)
+    ref.set_explore(not explore, 0)
+    for episode in range(2):   # second episode checks reset-in-place and the episode index of the stream
+        ref.next_episode()
+        r_obs, r_mask, r_rank = ref.reset()
+        obs, active = env.reset()
+        assert np.array_equal(obs.cpu().numpy(), r_obs)
+        assert np.array_equal(active.cpu().numpy().astype(np.uint64), r_mask)
+        rs = np.random.RandomState(11 + episode)
+        for t in range(T):
+            pl = rs.randint(0, n, size=(B, n)).astype(np.int32)
+            rsrc = rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32)
+            r_obs, r_rew, r_em, r_done = ref.step(pl, rsrc)
+            obs, rew, done, _, info = env.step(torch.as_tensor(pl).to(env.device), torch.as_tensor(rsrc).to(env.device))
+            assert np.array_equal(obs.cpu().numpy(), r_obs), t
+            assert np.array_equal(info["reward_raw"].cpu().numpy(), r_rew), t
+            assert np.array_equal(info["emitted"].cpu().numpy(), r_em) and np.array_equal(done.cpu().numpy(), r_done)
+            assert np.array_equal(env.rank.cpu().numpy(), ref.rank), t
+            assert np.array_equal(env.n_draws.cpu().numpy(), ref.n_draws), t
+            assert np.array_equal(env.step_latency.cpu().numpy(), ref.step_lat, equal_nan=True), t
+        st, rst = env.get_state(), ref.state()
+        for k in ("load", "queue", "sim_time", "elapsed", "step", "counts"):
+            assert np.array_equal(st[k], rst[k]), k
+        m, rm = env.episode_metrics().cpu().numpy(), ref.metrics()
+        assert np.array_equal(m[:, [1, 3, 4]], rm[:, [1, 3, 4]])
+        np.testing.assert_allclose(m, rm, rtol=1e-12, atol=0)
+    assert env.global_step_counter == ref.explore_counter
+
+
+def test_lane_packings_agree_and_absent_actions():
+    """16/32/64 lanes per environment give identical bits; a negative placement leaves the task undispatched."""
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = eo.default_config()
+    cfg.update(episode_length=60)
+    B, n = 130, 10
+    outs = []
+    rs = np.random.RandomState(3)
+    acts = [(rs.randint(-1, n, size=(B, n)).astype(np.int32), rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32))
+            for _ in range(60)]
+    ref = c_oracle.COracleEnv(cfg, B, seed=5, env_offset=0)
+    ref.set_explore(False, 0)
+    ref.next_episode()
+    ref.reset()
+    ref_trace = []
+    for pl, rsrc in acts:
+        o, r, e, d = ref.step(pl, rsrc)
+        ref_trace.append((o.copy(), r.copy()))
+    for lanes in (16, 32, 64):
+        env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=5)
+        env.set_lanes_per_env(lanes)
+        env.reset()
+        for (pl, rsrc), (ro, rr) in zip(acts, ref_trace):
+            obs, rew, done, _, info = env.step(torch.as_tensor(pl).cuda(), torch.as_tensor(rsrc).cuda())
+            assert np.array_equal(obs.cpu().numpy(), ro) and np.array_equal(info["reward_raw"].cpu().numpy(), rr)
+        outs.append(env.get_state())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k])
+
+
+def test_properties_at_65536_envs():
+    """Size-independent checks at configs[2]'s environment count: replicated environments stay identical,
+    counters are conserved, observations are consistent with the active mask."""
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = eo.default_config()
+    cfg.update(episode_length=100, disable_env_exploration=True)
+    B, n = 65536, 10
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=9)
+    obs, active = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tasks_acted = torch.zeros(B, dtype=torch.int64, device="cuda")
+    for t in range(100):
+        act_bits = active.clone()
+        pl = torch.randint(0, n, (B, n), device="cuda", generator=g, dtype=torch.int32)
+        rsrc = torch.rand((B, n), device="cuda", generator=g) * 0.9 + 0.1
+        row_nonzero = (obs.abs().sum(-1) > 0)
+        bits = ((act_bits.unsqueeze(1) >> torch.arange(n, device="cuda")) & 1).bool()
+        assert torch.equal(row_nonzero, bits)       # zero rows <=> no pending task
+        tasks_acted += bits.sum(1)
+        obs, rew, done, _, info = env.step(pl, rsrc)
+        assert bool((rew <= 0).all()) and bool(((rew == 0) | (info["emitted"] == 1)).all())
+    assert bool((done == 1).all())
+    st = env.get_state()
+    assert np.array_equal(st["counts"][:, 0], tasks_acted.cpu().numpy())
+    assert np.array_equal(st["counts"][:, 1] + st["counts"][:, 2], st["counts"][:, 0])
+    assert (st["step"] == 100).all() and np.all(st["load"] == 0.0)   # the unit quirk zeroes load every step
+    # agrees with the C restatement on a strided sample of environments
+    idx = np.arange(0, B, 4099)
+    for b in idx[:8]:
+        ref = c_oracle.COracleEnv(cfg, 1, seed=9, env_offset=int(b))
+        ref.set_explore(True, 0)
+        ref.next_episode()
+        r_obs, _, _ = ref.reset()
+        gg = torch.Generator(device="cuda").manual_seed(0)
+        # replay the same action stream for that environment
+        for t in range(100):
+            pl = torch.randint(0, n, (B, n), device="cuda", generator=gg, dtype=torch.int32)[b:b + 1].cpu().numpy()
+            rsrc = (torch.rand((B, n), device="cuda", generator=gg) * 0.9 + 0.1)[b:b + 1].cpu().numpy()
+            ref.step(pl, rsrc)
+        rst = ref.state()
+        assert rst["sim_time"][0] == st["sim_time"][b] and list(rst["counts"][0]) == list(st["counts"][b])
