@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the hot path (BASELINE.json: agent-steps/sec of the env step).
+
+Workload at N=1 = BASELINE.json configs[1]: "EdgeSimGym default topology, 4096 batched envs, random
+actions, step-only kernel on one MI355X".  One "step" = one em_step launch over the whole batch.
+Inputs (action pool, environment state) are resident in HBM before the timed region.  With N>1
+(torchrun, one rank per GPU) every rank steps its own 4096-environment shard: environments are
+independent, so there is no data-path collective and scaling is weak.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs B] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, HBM) and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes_per_env_step(n: int, rec_bytes: int) -> int:
+    """DESIGN.md 'algorithmic bytes': record read+written once, actions read, outputs written.
+    record = em_record_bytes (432 B at n=10); inputs placement i32 + resource f32 = 8n;
+    outputs dense obs 4n(n+4) + active u64 8 + rank i8 n + reward f64 8 + reward_seen f64 8 + emitted 1 + done 1."""
+    return 2 * rec_bytes + 8 * n + 4 * n * (n + 4) + 8 + n + 8 + 8 + 1 + 1
+
+
+def cpu_baseline(seconds_target: float = 12.0) -> dict:
+    """Times the line-for-line Python/numpy restatement of EdgeSimGym.step (oracle/) on ONE host core:
+    whole 1000-step episodes with random actions, exploration disabled, until ~seconds_target."""
+    from oracle import edge_env_oracle as eo
+    cfg = eo.default_config()
+    cfg["disable_env_exploration"] = True
+    env = eo.EdgeEnvOracle(cfg, eo.LegacyDraws(0))
+    n = env.n
+    rs = np.random.RandomState(1)
+    steps = 0
+    episodes = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds_target:
+        env.reset()
+        for _ in range(cfg["episode_length"]):
+            env.step(rs.randint(0, n, size=n), rs.uniform(0.1, 1.0, size=n).astype(np.float32))
+        steps += cfg["episode_length"]
+        episodes += 1
+    dt = time.perf_counter() - t0
+    out = {"value": steps * n / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{episodes} episodes x 1000 steps, 1 env, random actions, exploration off, "
+                     f"Python/numpy restatement (oracle/edge_env_oracle.py), {dt:.1f} s"}
+    # the plain-C restatement on the same workload shape, for scale (single core)
+    try:
+        from oracle import c_oracle
+        B = 256
+        cenv = c_oracle.COracleEnv(cfg, B, seed=1)
+        cenv.set_explore(True, 0)
+        pl = rs.randint(0, n, size=(B, n)).astype(np.int32)
+        rr = rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32)
+        cenv.next_episode()
+        cenv.reset()
+        t1 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t1 < 3.0:
+            for _ in range(50):
+                cenv.step(pl, rr)
+            k += 50
+        out["c_port_value"] = k * B * n / (time.perf_counter() - t1)
+    except Exception as e:  # pragma: no cover - informational only
+        out["c_port_error"] = repr(e)
+    out["host"] = {"nproc": os.cpu_count(), "cpu": _cpu_model()}
+    return out
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.env import BatchedEdgeSimGym
+
+    cfg = dict(ENV_CONFIG)
+    cfg["disable_env_exploration"] = True
+    B = args.envs
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B, latency_log_capacity=0)
+    n = env.n_nodes
+    T = env.episode_len
+    # pre-generated random actions, resident in HBM: placement ~ U{0..n-1}, resource ~ U(0.1, 1.0)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    POOL = 16
+    pool = [(torch.randint(0, n, (B, n), device=device, generator=gen, dtype=torch.int32),
+             (torch.rand((B, n), device=device, generator=gen) * 0.9 + 0.1).contiguous()) for _ in range(POOL)]
+    ptrs = [(p.data_ptr(), r.data_ptr()) for p, r in pool]
+    L, h, out = env._L, env._h, C.byref(env._out)
+    stream = torch.cuda.current_stream(device)
+    sptr = stream.cuda_stream
+
+    def run(k, counter):
+        for _ in range(k):
+            if counter[0] % T == 0:
+                env.reset()
+            pp, rr = ptrs[counter[0] % POOL]
+            rc = L.em_step(h, pp, rr, None, out, sptr)
+            if rc:
+                raise RuntimeError(L.em_last_error().decode())
+            counter[0] += 1
+
+    counter = [0]
+    run(args.warmup, counter)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.steps, counter)
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # parity spot check outside the timed region: done flags and a finite reward
+    assert bool(torch.isfinite(env.reward).all())
+
+    if rank == 0:
+        agent_steps = world * B * n * args.steps
+        bytes_launch = algorithmic_bytes_per_env_step(n, env.record_bytes) * B
+        launch_s = dev_ms * 1e-3 / args.steps          # HIP events on the launch stream, reset launches included
+        achieved = bytes_launch / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(str(B))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "agent-steps/sec (env step)",
+            "value": agent_steps / elapsed,
+            "unit": "agent-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "EdgeSimGym default topology, 4096 batched envs/GPU, random actions, step-only kernel",
+                       "n_envs_per_gpu": B, "n_nodes": n, "episode_length": T, "rng": "philox4x32-10 in-kernel",
+                       "exploration": "disabled", "lanes_per_env": 16},
+            "roofline": {"bound": "hbm", "kernel": "env_kernel<16,philox,step>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": bytes_launch, "avg_launch_us": launch_s * 1e6},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
