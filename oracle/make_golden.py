@@ -168,5 +168,130 @@ def main():
         run_scenario(*sc)
 
 
+
+
+# ------------------------------------------------------------------------------------------------
+# MAPPO goldens: one reference episode of MAPPOTrainer(seed=0) + the first update()
+# ------------------------------------------------------------------------------------------------
+def run_mappo_scenario(name="mappo_seed0_T200", seed=0, T=200):
+    import copy
+
+    import torch
+
+    MRRL, alg, trainer_mod = load_reference()
+    real_np = np
+    proxy = NumpyProxy(real_np)
+    eps_log = []
+
+    BaseNormal = alg.Normal
+
+    class RecordingNormal(BaseNormal):
+        """Normal whose rsample logs the standard-normal draw (same formula as torch's rsample)."""
+
+        def rsample(self, sample_shape=torch.Size()):
+            shape = self._extended_shape(sample_shape)
+            eps = torch.normal(torch.zeros(shape, dtype=self.loc.dtype), torch.ones(shape, dtype=self.loc.dtype))
+            eps_log.append(eps.detach().numpy().copy().reshape(-1))
+            return self.loc + eps * self.scale
+
+    MRRL.np = proxy
+    alg.Normal = RecordingNormal
+    try:
+        cfg = {**MRRL.ENV_CONFIG, "episode_length": T}
+        MRRL.EdgeSimGym._global_step_counter = 0
+        tr = trainer_mod.MAPPOTrainer(cfg, seed=seed, device="cpu")
+        n = cfg["n_nodes"]
+        init_params = {f"actor.{k}": v.detach().numpy().copy() for k, v in tr.mappo.actor.state_dict().items()}
+        init_params.update({f"critic.{k}": v.detach().numpy().copy() for k, v in tr.mappo.critic.state_dict().items()})
+        proxy.random.log.clear()
+        env_actions = []
+        orig_step = tr.env.step
+
+        def spy_step(actions):
+            pl = np.full(n, -1, np.int32)
+            rs = np.zeros(n, np.float32)
+            for k, a in actions.items():
+                i = int(k.split("_")[1])
+                pl[i] = a["placement"]
+                rs[i] = a["resource"][0]
+            env_actions.append((pl, rs))
+            return orig_step(actions)
+
+        tr.env.step = spy_step
+        counter0 = MRRL.EdgeSimGym._global_step_counter
+        stats = tr.train_episode(explore=True, record_buffer=True)
+        flat = list(proxy.random.log)
+        buf = tr.mappo.buffer.get()
+        L = len(buf["rewards"])
+        b_obs = np.array(buf["observations"], np.float32)
+        b_states = np.array(buf["states"], np.float32)
+        b_actions = np.array(buf["actions"], np.float32)
+        b_rewards = np.array(buf["rewards"], np.float64)
+        b_dones = np.array(buf["dones"], np.uint8)
+        b_logp = np.array(buf["log_probs"], np.float64)
+        b_values = np.array(buf["values"], np.float64)
+        adv, ret = tr.mappo.compute_gae(buf["rewards"], buf["values"], buf["dones"], 0)
+
+        m1 = copy.deepcopy(tr.mappo)
+        m1.num_sgd_iter = 1
+        loss1 = m1.update()
+        params1 = {f"actor.{k}": v.detach().numpy().copy() for k, v in m1.actor.state_dict().items()}
+        params1.update({f"critic.{k}": v.detach().numpy().copy() for k, v in m1.critic.state_dict().items()})
+        loss4 = tr.mappo.update()
+        params4 = {f"actor.{k}": v.detach().numpy().copy() for k, v in tr.mappo.actor.state_dict().items()}
+        params4.update({f"critic.{k}": v.detach().numpy().copy() for k, v in tr.mappo.critic.state_dict().items()})
+    finally:
+        MRRL.np = real_np
+        alg.Normal = BaseNormal
+
+    # structured env tape via the restatement (also re-checks draw order)
+    tape = eo.empty_tape(T + 1, n, a_slots=32)
+    ocfg = {**eo.default_config(), "episode_length": T}
+    orc = eo.EdgeEnvOracle(ocfg, eo.FlatReplay(flat), tape_out=tape)
+    orc.explore_counter = counter0
+    obs0, order = orc.reset()
+    step_obs = [obs0]
+    step_rank = [np.array([order.index(a) if a in order else -1 for a in range(n)], np.int8)]
+    step_reward, step_emitted = [], []
+    for t in range(T):
+        pl, rs = env_actions[t]
+        out = orc.step(np.where(pl < 0, 0, pl), rs, present={a for a in range(n) if pl[a] >= 0})
+        step_obs.append(out.obs)
+        step_rank.append(np.array([out.order.index(a) if a in out.order else -1 for a in range(n)], np.int8))
+        step_reward.append(out.reward)
+        step_emitted.append(out.reward_emitted)
+    assert orc.draws.pos == len(flat)
+    # the buffer must be the per-agent flattening of these steps (mappo_trainer.py:160-175)
+    i = 0
+    for t in range(T):
+        rk = step_rank[t]
+        for r in range(int((rk >= 0).sum())):
+            a = int(np.where(rk == r)[0][0])
+            assert np.array_equal(b_obs[i], step_obs[t][a]) and np.array_equal(b_states[i], step_obs[t].reshape(-1))
+            assert b_rewards[i] == (step_reward[t] if step_emitted[t] else 0.0)
+            i += 1
+    assert i == L
+    eps = np.concatenate(eps_log).reshape(L, n + 1).astype(np.float32)
+    out_path = os.path.join(GOLDEN, f"{name}.npz")
+    np.savez_compressed(
+        out_path, seed=seed, episode_length=T, n_nodes=n, explore_counter0=counter0,
+        episode_reward=stats["episode_reward"],
+        env_placement=np.array([a[0] for a in env_actions]), env_resource=np.array([a[1] for a in env_actions]),
+        step_obs=np.array(step_obs), step_rank=np.array(step_rank), step_reward=np.array(step_reward),
+        step_emitted=np.array(step_emitted),
+        buf_actions=b_actions, buf_logp=b_logp, buf_values=b_values, buf_dones=b_dones, buf_rewards=b_rewards,
+        noise=eps, gae_adv=np.array(adv, np.float64), gae_ret=np.array(ret, np.float64),
+        loss1=np.array([loss1["actor_loss"], loss1["critic_loss"], loss1["entropy"]]),
+        loss4=np.array([loss4["actor_loss"], loss4["critic_loss"], loss4["entropy"]]),
+        **{f"init.{k}": v for k, v in init_params.items()},
+        **{f"p1.{k}": v for k, v in params1.items()},
+        **{f"p4.{k}": v for k, v in params4.items()},
+        **{f"tape_{k}": v for k, v in tape.items()},
+    )
+    print(f"[golden] {out_path}: L={L}, episode_reward={stats['episode_reward']!r}, loss1={loss1}, loss4={loss4}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--mappo" not in sys.argv:
+        main()
+    run_mappo_scenario()

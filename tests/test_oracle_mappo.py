@@ -1,0 +1,80 @@
+"""Pins oracle/mappo_oracle.py (torch-CPU fp32 restatement) and the C GAE against the golden episode and
+update recorded from the imported reference MAPPOTrainer(seed=0) (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import c_oracle
+from oracle import mappo_oracle as mo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mappo_seed0_T200.npz")
+
+
+def load():
+    z = np.load(GOLD, allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    g["init"] = {k[5:]: g[k] for k in list(g) if k.startswith("init.")}
+    g["p1"] = {k[3:]: g[k] for k in list(g) if k.startswith("p1.")}
+    g["p4"] = {k[3:]: g[k] for k in list(g) if k.startswith("p4.")}
+    return g
+
+
+def flatten_buffer(g):
+    """Per-agent flattening of the steps in arrival order (mappo_trainer.py:160-175)."""
+    T, n = int(g["episode_length"]), int(g["n_nodes"])
+    obs, states, step_of = [], [], []
+    for t in range(T):
+        rk = g["step_rank"][t]
+        for r in range(int((rk >= 0).sum())):
+            a = int(np.where(rk == r)[0][0])
+            obs.append(g["step_obs"][t][a])
+            states.append(g["step_obs"][t].reshape(-1))
+            step_of.append(t)
+    return np.array(obs, np.float32), np.array(states, np.float32), np.array(step_of)
+
+
+def test_rollout_quantities():
+    g = load()
+    p = mo.to_torch(g["init"])
+    obs, states, step_of = flatten_buffer(g)
+    a, logp, mu = mo.sample(p, torch.as_tensor(obs), torch.as_tensor(g["noise"]))
+    np.testing.assert_allclose(a.numpy(), g["buf_actions"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(logp.numpy(), g["buf_logp"], rtol=1e-6, atol=1e-5)
+    v = mo.rollout_value(p, torch.as_tensor(states))
+    np.testing.assert_allclose(v.numpy(), g["buf_values"], rtol=1e-6, atol=1e-6)
+    n = int(g["n_nodes"])
+    i = 0
+    for t in range(int(g["episode_length"])):
+        rk = g["step_rank"][t]
+        for r in range(int((rk >= 0).sum())):
+            ag = int(np.where(rk == r)[0][0])
+            pl, rs = mo.format_env_action(g["buf_actions"][i], n)
+            assert pl == g["env_placement"][t][ag] and rs == g["env_resource"][t][ag]
+            i += 1
+    rew = np.where(g["step_emitted"], g["step_reward"], 0.0)
+    assert np.array_equal(rew[step_of], g["buf_rewards"])
+    assert float(rew.sum()) == float(g["episode_reward"]) or abs(rew.sum() - g["episode_reward"]) < 1e-9
+
+
+def test_gae_exact():
+    g = load()
+    adv, ret = mo.gae_flat(list(g["buf_rewards"]), list(g["buf_values"]), list(g["buf_dones"]))
+    assert np.array_equal(adv, g["gae_adv"]) and np.array_equal(ret, g["gae_ret"])
+    cadv, cret = c_oracle.gae(g["buf_rewards"], g["buf_values"], g["buf_dones"], 0.0, 0.99, 0.95)
+    assert np.array_equal(cadv, g["gae_adv"]) and np.array_equal(cret, g["gae_ret"])
+
+
+def test_update_matches_reference():
+    g = load()
+    obs, states, _ = flatten_buffer(g)
+    batch = {"obs": obs, "states": states, "actions": g["buf_actions"], "old_logp": g["buf_logp"],
+             "adv": g["gae_adv"], "returns": g["gae_ret"]}
+    p1, losses1, _, _, _ = mo.update(g["init"], batch, n_iter=1)
+    np.testing.assert_allclose(losses1[0], g["loss1"], rtol=1e-6, atol=1e-9)
+    for k, v in g["p1"].items():
+        np.testing.assert_allclose(p1[k], v, rtol=1e-6, atol=1e-8, err_msg=k)
+    p4, losses4, _, _, _ = mo.update(g["init"], batch, n_iter=4)
+    np.testing.assert_allclose(np.mean(np.array(losses4), axis=0), g["loss4"], rtol=1e-6, atol=1e-9)
+    for k, v in g["p4"].items():
+        np.testing.assert_allclose(p4[k], v, rtol=1e-5, atol=1e-7, err_msg=k)
