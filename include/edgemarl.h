@@ -128,6 +128,110 @@ int64_t em_n_envs(const em_handle *h);
 /* Kernel variant: lanes per environment (16/32/64); 0 restores the automatic choice. */
 int em_set_lanes_per_env(em_handle *h, int lanes);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * MAPPO side (reference mappo_algorithm.py / mappo_trainer.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Parameters of a 3-layer ReLU MLP in torch.nn.Linear layout (weight [out][in] row-major, float32):
+ * MAPPOActor fc1/fc2/mu (mappo_algorithm.py:28-41) or MAPPOCritic fc1/fc2/value_out (:76-90). */
+typedef struct em_mlp3 {
+    const float *w1, *b1;   /* [hidden][in_dim], [hidden] */
+    const float *w2, *b2;   /* [hidden][hidden], [hidden] */
+    const float *w3, *b3;   /* [out_dim][hidden], [out_dim] */
+    int32_t in_dim, hidden, out_dim;   /* hidden must be 64; in_dim <= 144; out_dim <= 16 */
+} em_mlp3;
+
+/* Device buffers of one rollout of `horizon` steps over n_envs environments; everything is
+ * allocated by the caller.  "entries" are acting (env, step, agent) transitions in (step, env,
+ * arrival-rank) order = RolloutBuffer rows (mappo_algorithm.py:93-131); "steps" are the (step, env)
+ * pairs with at least one acting agent, whose dense state row is the critic input
+ * (mappo_trainer.py:101-123).  The *_tb arrays are dense [horizon][n_envs]. */
+typedef struct em_rollout {
+    int64_t n_envs, capacity_entries, capacity_steps;
+    int32_t n_nodes, horizon;
+    float *ent_obs;        /* [E][n_nodes+4]  observation of the acting agent                     */
+    float *ent_action;     /* [E][n_nodes+1]  raw action vector (pre argmax/tanh)                  */
+    float *ent_logp;       /* [E]                                                                 */
+    int32_t *ent_env;      /* [E]                                                                 */
+    int8_t *ent_agent;     /* [E]                                                                 */
+    float *ent_adv;        /* [E]  GAE advantage (un-normalised), written by em_gae               */
+    float *ent_ret;        /* [E]  return = advantage + value                                     */
+    float *st_state;       /* [S][n_nodes*(n_nodes+4)]                                            */
+    float *st_value;       /* [S]  critic value of the pre-step state, de-normalised             */
+    int32_t *st_env;       /* [S]                                                                 */
+    int32_t *st_first;     /* [S]  first entry of this step                                       */
+    uint8_t *st_k;         /* [S]  number of entries of this step                                 */
+    double *reward_tb;     /* [T][B] reward as the trainer sees it (em_step_out.reward_seen)      */
+    uint8_t *done_tb;      /* [T][B]                                                              */
+    float *value_tb;       /* [T][B] value of steps with acting agents                            */
+    uint8_t *k_tb;         /* [T][B] acting agents                                                */
+    int32_t *first_tb;     /* [T][B] first entry                                                  */
+    int32_t *srow;         /* [B]    scratch: step row of the current step or -1                  */
+    int64_t *counters;     /* [T+1][4] {entry_base, n_entries, step_base, n_steps}; row 0 zeroed by the caller */
+    int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller */
+} em_rollout;
+
+/* y[rows][out_dim] = MLP(x[rows][ldx]) on the f32 matrix cores (MAPPOActor.forward / MAPPOCritic.forward). */
+int em_mlp3_forward(const em_mlp3 *net, const float *x, int64_t ldx, int64_t n_rows, float *y, void *stream);
+
+/* Record which agents act at step t: indexes and compacts the observations of the environment's
+ * current obs/active/rank outputs into the rollout buffers (RolloutBuffer.add of obs and state,
+ * mappo_trainer.py:160-175). */
+int em_rollout_index(const em_rollout *ro, int32_t t, const uint64_t *active, const int8_t *rank, const float *obs,
+                     void *stream);
+
+/* MAPPO.get_actions + MAPPOTrainer._format_env_actions + MAPPO.get_values for step t
+ * (mappo_algorithm.py:189-239, mappo_trainer.py:125-158): samples a = mu + sigma*eps for every entry
+ * of the step (noise = pre-drawn eps [E][n+1] aligned with the entries, or NULL for the in-kernel
+ * Philox/Box-Muller stream addressed by (seed; env_offset+env, episode, rng_step, agent); explore == 0 takes
+ * a = mu and log-prob 0), stores action/log-prob, writes
+ * the env actions placement/resource [n_envs][n_nodes] and the critic values. */
+int em_policy_step(const em_rollout *ro, int32_t t, const em_mlp3 *actor, const float *log_std, const em_mlp3 *critic,
+                   float value_norm_mean, float value_norm_var, const float *noise, int explore, uint64_t seed,
+                   uint32_t episode, uint32_t rng_step, uint64_t env_offset, int32_t *placement, float *resource,
+                   void *stream);
+
+/* MAPPO.compute_gae (mappo_algorithm.py:241-262) for every environment's segment of the transition
+ * list (next_value = 0 per segment, :284), float64 recursion, results rounded to float32 into
+ * ro->ent_adv / ro->ent_ret.  moments3 (device, 3 doubles) receives {count, sum, sum of squares} of the
+ * float32 advantages for the global normalisation (:293); partials is scratch of
+ * 3*ceil(n_envs/256) doubles. */
+int em_gae(const em_rollout *ro, double gamma, double lam, double *partials, int64_t partials_capacity,
+           double *moments3, void *stream);
+
+/* Floats per slab row used by the two gradient kernels below: all parameters of the network in the
+ * order [w1|b1|w2|b2|w3|b3|(log_std)] followed by 3 loss sums. */
+int64_t em_ppo_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor);
+
+/* One epoch of MAPPO.update for the shared actor (mappo_algorithm.py:302,306-309,317-320): recomputes
+ * mu(obs), the PPO-clip objective with the globally normalised advantages and the entropy bonus, and
+ * back-propagates on the matrix cores.  grad_out[ n_params ] = d(actor_loss + entropy_coeff * (-entropy))
+ * / d params for THIS rank's entries with the mean taken over n_global transitions (sum the outputs of
+ * all ranks for data parallelism).  loss3_out = {sum min(surr1,surr2), sum entropy, entries}.
+ * slab = scratch [n_waves][em_ppo_slab_floats]; n_waves = 4 * workgroups to launch. */
+int em_ppo_actor_grad(const em_mlp3 *actor, const float *log_std, const float *ent_obs, const float *ent_action,
+                      const float *ent_logp, const float *ent_adv, const double *adv_moments3, int64_t n_entries,
+                      int64_t n_global, float clip, float entropy_coeff, float *slab, int64_t n_waves,
+                      float *grad_out, float *loss3_out, void *stream);
+
+/* Same for the central critic (mappo_algorithm.py:303,312-314): value_loss_coeff * 0.5 * mean(e^2) with
+ * e = normalise(v) - normalise(return); the critic is evaluated once per (env, step) and weighted by its
+ * k transitions, which equals the reference's per-transition evaluation of identical states.
+ * loss3_out = {sum e^2, 0, transitions}. */
+int em_ppo_critic_grad(const em_mlp3 *critic, const float *st_state, const int32_t *st_first, const uint8_t *st_k,
+                       const float *ent_ret, int64_t n_steps, int64_t n_global, float value_loss_coeff,
+                       float value_norm_mean, float value_norm_var, float *slab, int64_t n_waves, float *grad_out,
+                       float *loss3_out, void *stream);
+
+/* clip_grad_norm_ on each network separately (mappo_algorithm.py:328-329) then torch.optim.Adam's
+ * update (:331-332) on flat float32 parameter/moment buffers; step counts from 1.
+ * norms2_out (optional) receives the two pre-clip gradient norms. */
+int em_adam_step(float *actor_param, const float *actor_grad, float *actor_m, float *actor_v, int64_t n_actor,
+                 double lr_actor, float *critic_param, const float *critic_grad, float *critic_m, float *critic_v,
+                 int64_t n_critic, double lr_critic, int64_t step, double beta1, double beta2, double eps,
+                 double max_grad_norm, float *norms2_out, void *stream);
+
 int em_abi_version(void);
 const char *em_last_error(void);
 

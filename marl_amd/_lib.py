@@ -37,6 +37,21 @@ class EmStepOut(C.Structure):
     ]
 
 
+class EmMlp3(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class EmRollout(C.Structure):
+    _fields_ = [("n_envs", C.c_int64), ("capacity_entries", C.c_int64), ("capacity_steps", C.c_int64),
+                ("n_nodes", C.c_int32), ("horizon", C.c_int32)] + [
+        (name, C.c_void_p) for name in (
+            "ent_obs", "ent_action", "ent_logp", "ent_env", "ent_agent", "ent_adv", "ent_ret",
+            "st_state", "st_value", "st_env", "st_first", "st_k",
+            "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "counters", "err_flag")]
+
+
 _lib = None
 
 
@@ -68,6 +83,20 @@ def lib() -> C.CDLL:
     L.em_n_envs.argtypes = [vp]
     L.em_n_envs.restype = i64
     L.em_set_lanes_per_env.argtypes = [vp, i32]
+    L.em_mlp3_forward.argtypes = [C.POINTER(EmMlp3), vp, i64, i64, vp, vp]
+    L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
+    L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
+                                 C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    f32, f64 = C.c_float, C.c_double
+    L.em_gae.argtypes = [C.POINTER(EmRollout), f64, f64, vp, i64, vp, vp]
+    L.em_ppo_slab_floats.argtypes = [C.c_int32, C.c_int32, i32]
+    L.em_ppo_slab_floats.restype = i64
+    L.em_ppo_actor_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp, i64, vp, vp, vp]
+    L.em_ppo_critic_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, i64, i64, f32, f32, f32, vp, i64, vp, vp, vp]
+    L.em_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, vp, vp, vp, vp, i64, f64, i64, f64, f64, f64, f64, vp, vp]
+    for name in ("em_mlp3_forward", "em_rollout_index", "em_policy_step", "em_gae", "em_ppo_actor_grad",
+                 "em_ppo_critic_grad", "em_adam_step"):
+        getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
                  "em_get_state", "em_set_lanes_per_env"):
         getattr(L, name).restype = C.c_int

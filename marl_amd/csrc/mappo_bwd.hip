@@ -1,0 +1,613 @@
+// mappo_bwd.hip - update-side MAPPO kernels for MI355X (gfx950):
+//   * gae_kernel: reverse scan of MAPPO.compute_gae (mappo_algorithm.py:241-262) over each environment's
+//     segment of the flattened per-agent transition list, float64, one lane per environment, plus the
+//     moments of the advantages for the global normalisation (mappo_algorithm.py:293)
+//   * mlp3_bwd_kernel: fused forward-recompute + PPO loss + backward of the actor (PPO-clip + entropy,
+//     mappo_algorithm.py:302-309,317-320) or the critic (value MSE through the normaliser, :303,312-314)
+//     on the f32 matrix cores; weight gradients accumulate in registers per wavefront and leave as one
+//     slab row per wavefront (deterministic, no atomics)
+//   * reduce_slabs_kernel, adam_kernel: slab reduction, clip_grad_norm_ (:328-329) and Adam (:331-332)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "edgemarl.h"
+#include "em_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int HID = 64;
+constexpr int TS = 17;      // row stride of the transpose scratch (floats)
+constexpr int S2 = 66;      // LDS row stride of the 64-wide weight matrices (2*odd: conflict-free A-fragment reads)
+
+// ------------------------------------------------------------------------------------------------
+// GAE
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gae_kernel(int64_t B, int T, const double* __restrict__ reward_tb,
+                                                  const float* __restrict__ value_tb, const uint8_t* __restrict__ done_tb,
+                                                  const uint8_t* __restrict__ k_tb, const int32_t* __restrict__ first_tb,
+                                                  double gamma, double lam, float* __restrict__ adv,
+                                                  float* __restrict__ ret, double* __restrict__ partials)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (b < B) {
+        double gae = 0.0, v_next = 0.0;   // next_value = 0 closes every environment's segment (:284)
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t i = (int64_t)t * B + b;
+            const int k = k_tb[i];
+            if (k == 0) continue;
+            const double r = reward_tb[i], v = (double)value_tb[i];
+            const double nd = 1.0 - (double)done_tb[i];
+            const int64_t first = first_tb[i];
+            for (int j = k - 1; j >= 0; --j) {
+                const double nv = (j == k - 1) ? v_next : v;      // same-step entries chain through each other
+                const double delta = r + gamma * nv * nd - v;
+                gae = delta + gamma * lam * nd * gae;
+                const float a32 = (float)gae;
+                adv[first + j] = a32;
+                ret[first + j] = (float)(gae + v);
+                s0 += 1.0; s1 += (double)a32; s2 += (double)a32 * (double)a32;
+            }
+            v_next = v;
+        }
+    }
+    // block reduction of the moments (fixed order: deterministic)
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[3 * blockIdx.x + 0] = red[0][0];
+        partials[3 * blockIdx.x + 1] = red[1][0];
+        partials[3 * blockIdx.x + 2] = red[2][0];
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int64_t n_blocks,
+                                                           double* __restrict__ moments)
+{
+    __shared__ double red[3][256];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = threadIdx.x; i < n_blocks; i += 256)
+        for (int c = 0; c < 3; ++c) s[c] += partials[3 * i + c];
+    for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) moments[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward-recompute + loss + backward
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    em_mlp3 net;
+    const float* x;            // [rows][ldx]
+    int64_t ldx, n_rows;
+    float* slab;               // [n_waves][slab_stride]
+    int64_t slab_stride;
+    float inv_L;               // 1 / global number of transitions
+    // actor
+    const float* log_std;      // [O]
+    const float* action;       // [rows][O]
+    const float* old_logp;     // [rows]
+    const float* adv;          // [rows] un-normalised
+    const double* moments;     // {count, sum, sum of squares} of the advantages (global)
+    float clip, ecoef;
+    // critic
+    const int32_t* st_first;   // [rows]
+    const uint8_t* st_k;       // [rows]
+    const float* ent_ret;      // [E]
+    float vcoef, norm_mean, norm_scale;
+};
+
+template <int KU, bool ACTOR>
+__global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int K1 = a.net.in_dim, O = a.net.out_dim;
+    constexpr int K1P = KU * 16;
+    constexpr int S1 = (K1P + 2) | 2;                 // 2*odd >= K1P + 2 when K1P is a multiple of 16
+    float* W1s = lds;                                 // [64][S1]
+    float* W2s = W1s + HID * S1;                      // [64][S2]
+    float* W3s = W2s + HID * S2;                      // [16][S2] (rows >= O are zero)
+    float* scr = W3s + 16 * S2 + wave * (HID * TS);   // per-wavefront transpose scratch [64][TS]
+
+    for (int i = threadIdx.x; i < HID * K1P; i += 256) {
+        const int r = i / K1P, k = i - r * K1P;
+        W1s[r * S1 + k] = k < K1 ? a.net.w1[r * K1 + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < HID * HID; i += 256) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
+    for (int i = threadIdx.x; i < 16 * HID; i += 256) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
+    __syncthreads();
+
+    f32x4 bias1[4], bias2[4], bias3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bias1[t][r] = a.net.b1[16 * t + 4 * q + r];
+            bias2[t][r] = a.net.b2[16 * t + 4 * q + r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
+
+    // gradient accumulators (per wavefront, whole launch)
+    f32x4 gW1[4][KU], gW2[4][4], gW3[4], gb1[4], gb2[4], gb3, gls;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) gW1[t][u] = zero4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gW2[t][u] = zero4;
+        gW3[t] = zero4; gb1[t] = zero4; gb2[t] = zero4;
+    }
+    gb3 = zero4; gls = zero4;
+    float loss_sum = 0.0f, aux_sum = 0.0f, cnt_sum = 0.0f;
+
+    float adv_mean = 0.0f, adv_den = 1.0f, sd[4] = {1.f, 1.f, 1.f, 1.f}, ls[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACTOR) {
+        const double n = a.moments[0], s1 = a.moments[1], s2 = a.moments[2];
+        const double mean = s1 / n;
+        double var = (s2 - s1 * s1 / n) / (n - 1.0);              // torch.std: unbiased
+        if (!(var > 0.0)) var = 0.0;
+        adv_mean = (float)mean;
+        adv_den = (float)sqrt(var) + 1e-8f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) { ls[r] = a.log_std[4 * q + r]; sd[r] = expf(ls[r]); }
+    }
+
+    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    const int64_t n_tiles = (a.n_rows + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + c;
+        const bool valid = row < a.n_rows;
+        const float* xr = a.x + (valid ? row : 0) * a.ldx;
+        float xb[KU * 4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = 16 * u + 4 * q;
+            if (vec_ok && k + 3 < K1) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                xb[u * 4 + 0] = v.x; xb[u * 4 + 1] = v.y; xb[u * 4 + 2] = v.z; xb[u * 4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xb[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+            }
+        }
+        if (!valid) {
+#pragma unroll
+            for (int s = 0; s < KU * 4; ++s) xb[s] = 0.0f;
+        }
+        // ---- forward (recompute) -------------------------------------------------------------------
+        f32x4 h1[4], h2[4], y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
+#pragma unroll
+        for (int s = 0; s < KU * 4; ++s) {
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2s[(16 * t + c) * S2 + k], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+        y = bias3;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+            y = __builtin_amdgcn_mfma_f32_16x16x4f32(W3s[c * S2 + k], h2[s >> 2][s & 3], y, 0, 0, 0);
+        }
+
+        // ---- loss and dL/dy in accumulator layout: dy[r] = d/d out[row c][o = 4q + r] --------------
+        f32x4 dy = zero4;
+        if constexpr (ACTOR) {
+            float d[4], lp = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * q + r;
+                d[r] = 0.0f;
+                if (o < O && valid) {
+                    d[r] = a.action[row * O + o] - y[r];
+                    lp += -(d[r] * d[r]) / (2.0f * (sd[r] * sd[r])) - ls[r] - 0.91893853320467274f;
+                }
+            }
+            lp += __shfl_xor(lp, 16);
+            lp += __shfl_xor(lp, 32);
+            float g_lp = 0.0f;
+            if (valid) {
+                const float A = (a.adv[row] - adv_mean) / adv_den;          // mappo_algorithm.py:293
+                const float ratio = expf(lp - a.old_logp[row]);             // :306
+                const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+                const float rc = fminf(fmaxf(ratio, lo), hi);
+                const float su1 = ratio * A, su2 = rc * A;                  // :307-308
+                const float in_range = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+                // d min(s1,s2)/d ratio with autograd's tie rule (equal inputs share the gradient)
+                const float wgt = su1 < su2 ? 1.0f : (su1 == su2 ? 0.5f + 0.5f * in_range : in_range);
+                g_lp = -(A * ratio * wgt) * a.inv_L;                        // d(-mean(min))/d logp
+                if (q == 0) { loss_sum += fminf(su1, su2); cnt_sum += 1.0f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * q + r;
+                if (o < O && valid) {
+                    const float iv = 1.0f / (sd[r] * sd[r]);
+                    dy[r] = g_lp * d[r] * iv;                               // d logp / d mu
+                    gls[r] += g_lp * (d[r] * d[r] * iv - 1.0f) - a.ecoef * a.inv_L;   // d logp / d log_std ; entropy bonus
+                }
+            }
+            if (valid && q == 0) {
+                float ent = 0.0f;
+                for (int o = 0; o < O; ++o) ent += 0.5f + 0.91893853320467274f + a.log_std[o];
+                aux_sum += ent;
+            }
+        } else {
+            if (valid && q == 0) {
+                const float v = y[0];
+                const int k = a.st_k[row];
+                const int64_t first = a.st_first[row];
+                float gsum = 0.0f;
+                for (int j = 0; j < k; ++j) {
+                    const float e = (v - a.norm_mean) / a.norm_scale - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
+                    gsum += e;
+                    loss_sum += e * e;                                      // :314 before the 0.5 and the mean
+                }
+                cnt_sum += (float)k;
+                dy[0] = a.vcoef * a.inv_L * gsum / a.norm_scale;            // d(vcoef * 0.5 * mean(e^2)) / dv
+            }
+        }
+
+        // ---- backward through layer 3 and 2 ----------------------------------------------------------
+        gb3 += dy;
+        f32x4 dz2[4], dz1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dz2[t] = zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 4q + r
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W3s[(4 * q + r) * S2 + 16 * t + c], dy[r], dz2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { dz1[t] = zero4; gb2[t] += dz2[t]; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2s[k * S2 + 16 * t + c], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
+            gb1[t] += dz1[t];
+        }
+
+        // ---- weight gradients: reduction over the 16 batch rows of the tile ---------------------------
+        // transposed fragments: trX[t][s] = X[feature 16t + c][batch 4s + q]
+        float tr_a[4][4], tr_b[4][4];
+        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = m[t][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) out[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
+        float tr_y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scr[(4 * q + r) * TS + c] = dy[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) tr_y[s] = scr[c * TS + 4 * s + q];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        transpose64(h2, tr_b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[t], 0, 0, 0);
+        // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
+        transpose64(dz2, tr_a);
+        transpose64(h1, tr_b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+                for (int t1 = 0; t1 < 4; ++t1)
+                    gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+        // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
+        transpose64(dz1, tr_a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t rb = tile * 16 + 4 * s + q;
+            const float* xrow = a.x + (rb < a.n_rows ? rb : 0) * a.ldx;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int i = 16 * u + c;
+                const float xv = (rb < a.n_rows && i < K1) ? xrow[i] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- write this wavefront's slab row: [w1 | b1 | w2 | b2 | w3 | b3 | (log_std) | loss, aux, count] ----
+    float* out = a.slab + ((int64_t)blockIdx.x * 4 + wave) * a.slab_stride;
+    const int o_b1 = HID * K1, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID, o_w3 = o_b2 + HID, o_b3 = o_w3 + O * HID;
+    const int o_ls = o_b3 + O, o_loss = ACTOR ? o_ls + O : o_ls;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * q + r;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int i = 16 * u + c;
+                if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+            }
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
+        }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) out[o_w3 + (4 * q + r) * HID + 16 * t + c] = gW3[t][r];
+    // bias-type gradients: reduce the 16 lanes that share q (fixed butterfly order)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                gb1[t][r] += __shfl_xor(gb1[t][r], m);
+                gb2[t][r] += __shfl_xor(gb2[t][r], m);
+            }
+            gb3[r] += __shfl_xor(gb3[r], m);
+            gls[r] += __shfl_xor(gls[r], m);
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        loss_sum += __shfl_xor(loss_sum, m);
+        aux_sum += __shfl_xor(aux_sum, m);
+        cnt_sum += __shfl_xor(cnt_sum, m);
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[o_b1 + 16 * t + 4 * q + r] = gb1[t][r];
+                out[o_b2 + 16 * t + 4 * q + r] = gb2[t][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) {
+                out[o_b3 + 4 * q + r] = gb3[r];
+                if constexpr (ACTOR) out[o_ls + 4 * q + r] = gls[r];
+            }
+    }
+    if (lane == 0) { out[o_loss] = loss_sum; out[o_loss + 1] = aux_sum; out[o_loss + 2] = cnt_sum; }
+}
+
+// grads[p] = sum over slab rows, fixed order
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int64_t n_rows, int64_t stride,
+                                                           int64_t n_cols, float* __restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_cols) return;
+    float s = 0.0f;
+    for (int64_t r = 0; r < n_rows; ++r) s += slab[r * stride + p];
+    out[p] = s;
+}
+
+// clip_grad_norm_ over [0,n) followed by torch.optim.Adam's single-tensor update; one workgroup per parameter group
+struct AdamGroup {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;
+    float step_size, one_m_beta1, beta2, one_m_beta2, eps, max_norm;   // step_size = lr / (1 - beta1^step)
+    float bias_c2_sqrt;             // sqrt(1 - beta2^step)
+};
+
+__global__ __launch_bounds__(1024) void adam_kernel(const AdamGroup g0, const AdamGroup g1, float* __restrict__ norms_out)
+{
+    const AdamGroup& g = blockIdx.x == 0 ? g0 : g1;
+    __shared__ double red[1024];
+    double ss = 0.0;
+    for (int64_t i = threadIdx.x; i < g.n; i += 1024) ss += (double)g.grad[i] * (double)g.grad[i];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float total_norm = (float)sqrt(red[0]);
+    float coef = g.max_norm / (total_norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (threadIdx.x == 0 && norms_out) norms_out[blockIdx.x] = total_norm;
+    const float step_size = g.step_size;
+    for (int64_t i = threadIdx.x; i < g.n; i += 1024) {
+        const float gr = g.grad[i] * coef;
+        const float m = g.exp_avg[i] + (gr - g.exp_avg[i]) * g.one_m_beta1;           // lerp_
+        const float v = g.exp_avg_sq[i] * g.beta2 + g.one_m_beta2 * gr * gr;           // mul_().addcmul_()
+        g.exp_avg[i] = m;
+        g.exp_avg_sq[i] = v;
+        const float denom = sqrtf(v) / g.bias_c2_sqrt + g.eps;
+        g.param[i] = g.param[i] - step_size * (m / denom);                                // addcdiv_
+    }
+}
+
+int check_net(const em_mlp3* net)
+{
+    if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3)
+        return em::fail(EM_ERR_INVALID, "mlp3: null parameter pointer");
+    if (net->hidden != HID || net->in_dim < 1 || net->in_dim > 144 || net->out_dim < 1 || net->out_dim > 16)
+        return em::fail(EM_ERR_INVALID, "mlp3: unsupported shape (hidden 64, in_dim<=144, out_dim<=16)");
+    return EM_OK;
+}
+
+template <bool ACTOR>
+int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
+{
+    const int ku = (ba.net.in_dim + 15) / 16;
+    const int s1 = ((ku * 16 + 2) | 2);
+    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 4 * HID * TS);
+    const dim3 grid((unsigned)(n_waves / 4)), block(256);
+#define EM_BWD(KU_)                                                                                               \
+    case KU_: {                                                                                                   \
+        if (lds > 64 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)mlp3_bwd_kernel<KU_, ACTOR>,                           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+            if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                   \
+        }                                                                                                         \
+        hipLaunchKernelGGL((mlp3_bwd_kernel<KU_, ACTOR>), grid, block, lds, s, ba);                               \
+    } break
+    switch (ku) {
+        EM_BWD(1); EM_BWD(2); EM_BWD(3); EM_BWD(4); EM_BWD(5); EM_BWD(6); EM_BWD(7); EM_BWD(8); EM_BWD(9);
+        default: return em::fail(EM_ERR_INVALID, "mlp3 backward: unsupported in_dim");
+    }
+#undef EM_BWD
+    return em::hip_check(hipGetLastError(), "mlp3_bwd_kernel launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+int em_gae(const em_rollout* ro, double gamma, double lam, double* partials, int64_t partials_capacity, double* moments3,
+           void* stream)
+{
+    if (!ro || !partials || !moments3) return em::fail(EM_ERR_INVALID, "em_gae: null argument");
+    const int64_t blocks = (ro->n_envs + 255) / 256;
+    if (partials_capacity < 3 * blocks) return em::fail(EM_ERR_INVALID, "em_gae: partials buffer needs %lld doubles", (long long)(3 * blocks));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gae_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ro->n_envs, ro->horizon, ro->reward_tb,
+                       ro->value_tb, ro->done_tb, ro->k_tb, ro->first_tb, gamma, lam, ro->ent_adv, ro->ent_ret, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partials, blocks, moments3);
+    return em::hip_check(hipGetLastError(), "gae launch");
+}
+
+int64_t em_ppo_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor)
+{
+    return (int64_t)HID * in_dim + HID + HID * HID + HID + (int64_t)out_dim * HID + out_dim + (is_actor ? out_dim : 0) + 3;
+}
+
+int em_ppo_actor_grad(const em_mlp3* actor, const float* log_std, const float* ent_obs, const float* ent_action,
+                      const float* ent_logp, const float* ent_adv, const double* adv_moments3, int64_t n_entries,
+                      int64_t n_global, float clip, float entropy_coeff, float* slab, int64_t n_waves, float* grad_out,
+                      float* loss3_out, void* stream)
+{
+    int rc = check_net(actor);
+    if (rc) return rc;
+    if (!log_std || !ent_obs || !ent_action || !ent_logp || !ent_adv || !adv_moments3 || !slab || !grad_out || !loss3_out)
+        return em::fail(EM_ERR_INVALID, "em_ppo_actor_grad: null argument");
+    if (n_entries < 1 || n_global < n_entries || n_waves < 4 || (n_waves & 3))
+        return em::fail(EM_ERR_INVALID, "em_ppo_actor_grad: bad sizes");
+    BwdArgs ba;
+    std::memset(&ba, 0, sizeof ba);
+    ba.net = *actor; ba.x = ent_obs; ba.ldx = actor->in_dim; ba.n_rows = n_entries; ba.slab = slab;
+    ba.slab_stride = em_ppo_slab_floats(actor->in_dim, actor->out_dim, 1);
+    ba.inv_L = 1.0f / (float)n_global;
+    ba.log_std = log_std; ba.action = ent_action; ba.old_logp = ent_logp; ba.adv = ent_adv; ba.moments = adv_moments3;
+    ba.clip = clip; ba.ecoef = entropy_coeff;
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_bwd<true>(ba, n_waves, s);
+    if (rc) return rc;
+    const int64_t np = ba.slab_stride - 3;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
+    return em::hip_check(hipGetLastError(), "actor grad launch");
+}
+
+int em_ppo_critic_grad(const em_mlp3* critic, const float* st_state, const int32_t* st_first, const uint8_t* st_k,
+                       const float* ent_ret, int64_t n_steps, int64_t n_global, float value_loss_coeff,
+                       float value_norm_mean, float value_norm_var, float* slab, int64_t n_waves, float* grad_out,
+                       float* loss3_out, void* stream)
+{
+    int rc = check_net(critic);
+    if (rc) return rc;
+    if (!st_state || !st_first || !st_k || !ent_ret || !slab || !grad_out || !loss3_out)
+        return em::fail(EM_ERR_INVALID, "em_ppo_critic_grad: null argument");
+    if (n_steps < 1 || n_global < 1 || n_waves < 4 || (n_waves & 3)) return em::fail(EM_ERR_INVALID, "em_ppo_critic_grad: bad sizes");
+    BwdArgs ba;
+    std::memset(&ba, 0, sizeof ba);
+    ba.net = *critic; ba.x = st_state; ba.ldx = critic->in_dim; ba.n_rows = n_steps; ba.slab = slab;
+    ba.slab_stride = em_ppo_slab_floats(critic->in_dim, critic->out_dim, 0);
+    ba.inv_L = 1.0f / (float)n_global;
+    ba.st_first = st_first; ba.st_k = st_k; ba.ent_ret = ent_ret;
+    ba.vcoef = value_loss_coeff; ba.norm_mean = value_norm_mean; ba.norm_scale = sqrtf(value_norm_var + 1e-8f);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_bwd<false>(ba, n_waves, s);
+    if (rc) return rc;
+    const int64_t np = ba.slab_stride - 3;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
+    return em::hip_check(hipGetLastError(), "critic grad launch");
+}
+
+int em_adam_step(float* actor_param, const float* actor_grad, float* actor_m, float* actor_v, int64_t n_actor, double lr_actor,
+                 float* critic_param, const float* critic_grad, float* critic_m, float* critic_v, int64_t n_critic,
+                 double lr_critic, int64_t step, double beta1, double beta2, double eps, double max_grad_norm, float* norms2_out,
+                 void* stream)
+{
+    if (!actor_param || !actor_grad || !actor_m || !actor_v || !critic_param || !critic_grad || !critic_m || !critic_v)
+        return em::fail(EM_ERR_INVALID, "em_adam_step: null argument");
+    if (step < 1) return em::fail(EM_ERR_INVALID, "em_adam_step: step counts from 1");
+    AdamGroup g[2];
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    g[0] = {actor_param, actor_grad, actor_m, actor_v, n_actor, (float)((double)lr_actor / bc1), omb1, (float)beta2, omb2, (float)eps, (float)max_grad_norm, (float)sqrt(bc2)};
+    g[1] = {critic_param, critic_grad, critic_m, critic_v, n_critic, (float)((double)lr_critic / bc1), omb1, (float)beta2, omb2, (float)eps, (float)max_grad_norm, (float)sqrt(bc2)};
+    hipLaunchKernelGGL(adam_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, g[0], g[1], norms2_out);
+    return em::hip_check(hipGetLastError(), "adam launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// mappo_fwd.hip - rollout-side MAPPO kernels for MI355X (gfx950):
+//   * fused 3-layer MLP forward on the f32 matrix cores (v_mfma_f32_16x16x4_f32), used for the shared
+//     actor (MAPPOActor.forward, mappo_algorithm.py:36-41) and the central critic (MAPPOCritic.forward, :83-90)
+//   * policy epilogue: Gaussian sample + log-prob (mappo_algorithm.py:62-71,209-213) and the trainer's
+//     action formatting (mappo_trainer.py:125-158), scattered into the dense env action arrays
+//   * value epilogue: ValueNormalizer.denormalize (mappo_algorithm.py:384-386)
+//   * trajectory indexing/compaction of the acting agents (RolloutBuffer.add, mappo_algorithm.py:104-111;
+//     MAPPOTrainer._store_transition, mappo_trainer.py:160-175)
+//
+// MLP formulation: the kernel computes the TRANSPOSED problem  H^T = W . X^T  so that the accumulator
+// tile of one layer (features on registers/lane-quads, batch rows on lane&15) is, register by
+// register, a valid B operand of the next layer's MFMA: activations never leave the register file.
+// The reduction index of every layer is enumerated as k = 16*u + 4*(lane>>4) + r  (u: 16-wide block,
+// r: register), and the weight fragments (A operands) are loaded once per wavefront in that same
+// order and stay in registers for the whole launch.  One wavefront processes 16 batch rows per tile.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "edgemarl.h"
+#include "em_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HID = 64;   // hidden width of both networks (mappo_algorithm.py:28,76)
+
+struct FwdArgs {
+    em_mlp3 net;
+    const float* x;            // [rows][ldx]
+    int64_t ldx;
+    int64_t n_rows;            // used when dyn == nullptr
+    const int64_t* dyn;        // optional {row_base, n_rows} in device memory
+    float* y;                  // MODE 0: [rows][out_dim]
+    // policy epilogue (MODE 1)
+    const float* log_std;      // [out_dim]
+    const float* noise;        // [rows][out_dim] standard normal draws, or nullptr for in-kernel Philox
+    float* ent_action;         // [rows][out_dim]
+    float* ent_logp;           // [rows]
+    const int32_t* ent_env;    // [rows]
+    const int8_t* ent_agent;   // [rows]
+    int32_t* placement;        // [n_envs][n_nodes]
+    float* resource;           // [n_envs][n_nodes]
+    int32_t n_nodes, explore;
+    uint32_t seed_lo, seed_hi, episode, step, env_offset, pad;
+    // value epilogue (MODE 2)
+    float* st_value;           // [rows]
+    const int32_t* st_env;     // [rows]
+    float* value_tb;           // dense [n_envs] slice of this step, or nullptr
+    float norm_mean, norm_scale;
+};
+
+__device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// two standard normals from two 32-bit words (Box-Muller, f32)
+__device__ inline void box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
+{
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.2831853071795865f * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+enum { P_NOISE = 8 };
+
+template <int KU, int MODE>
+__global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int K1 = a.net.in_dim, O = a.net.out_dim;
+    int64_t row_base = 0, n_rows = a.n_rows;
+    if (a.dyn) { row_base = a.dyn[0]; n_rows = a.dyn[1]; }
+    const int64_t n_tiles = (n_rows + 15) >> 4;
+    if ((int64_t)blockIdx.x * 4 + wave >= n_tiles) return;
+
+    // ---- weight fragments (A operands) and biases, resident in registers ----------------------------
+    float a1[4][KU * 4], a2[4][16], a3[16];
+    f32x4 bias1[4], bias2[4], bias3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * u + 4 * q + r;
+                a1[t][u * 4 + r] = k < K1 ? a.net.w1[(16 * t + c) * K1 + k] : 0.0f;
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a2[t][s] = a.net.w2[(16 * t + c) * HID + 16 * (s >> 2) + 4 * q + (s & 3)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bias1[t][r] = a.net.b1[16 * t + 4 * q + r];
+            bias2[t][r] = a.net.b2[16 * t + 4 * q + r];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a3[s] = c < O ? a.net.w3[c * HID + 16 * (s >> 2) + 4 * q + (s & 3)] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
+
+    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + c;          // row relative to row_base
+        const bool valid = row < n_rows;
+        const float* xr = a.x + (row_base + (valid ? row : 0)) * a.ldx;
+        float xb[KU * 4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = 16 * u + 4 * q;
+            if (vec_ok && k + 3 < K1) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                xb[u * 4 + 0] = v.x; xb[u * 4 + 1] = v.y; xb[u * 4 + 2] = v.z; xb[u * 4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xb[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+            }
+        }
+        if (!valid) {
+#pragma unroll
+            for (int s = 0; s < KU * 4; ++s) xb[s] = 0.0f;
+        }
+        f32x4 h1[4], h2[4], y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
+#pragma unroll
+        for (int s = 0; s < KU * 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][s], xb[s], h1[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t][s], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+        y = bias3;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], h2[s >> 2][s & 3], y, 0, 0, 0);
+        // y[r] = out[row][o = 4q + r]
+
+        const int64_t grow = row_base + row;
+        if constexpr (MODE == 0) {
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < O) a.y[grow * O + 4 * q + r] = y[r];
+            }
+        } else if constexpr (MODE == 2) {
+            if (valid && q == 0) {
+                const float v = y[0] * a.norm_scale + a.norm_mean;     // denormalize, mappo_algorithm.py:384-386
+                a.st_value[grow] = v;
+                if (a.value_tb) a.value_tb[a.st_env[grow]] = v;
+            }
+        } else {
+            // ---- policy epilogue ---------------------------------------------------------------------
+            const int n = a.n_nodes;
+            const int env = valid ? a.ent_env[grow] : 0;
+            const int agent = valid ? (int)a.ent_agent[grow] : 0;
+            float act[4];
+            float lp = 0.0f;
+            float best = -__builtin_inff();
+            int best_i = 1 << 20;
+            bool all_zero = true;
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+            if (a.explore && !a.noise)
+                rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step, (P_NOISE << 24) | ((uint32_t)agent << 4) | (uint32_t)q,
+                              a.seed_lo, a.seed_hi);
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.explore && !a.noise) { box_muller(rnd.x, rnd.y, z[0], z[1]); box_muller(rnd.z, rnd.w, z[2], z[3]); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * q + r;
+                const bool on = o < O;
+                float v = y[r];
+                if (a.explore && on) {
+                    const float ls = a.log_std[o];
+                    const float sd = expf(ls);
+                    const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
+                    v = y[r] + e * sd;                                  // rsample, mappo_algorithm.py:65
+                    const float d = v - y[r];
+                    lp += -(d * d) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f;   // Normal.log_prob
+                }
+                act[r] = v;
+                if (on && o < n) {
+                    if (fabsf(v) > 1e-8f) all_zero = false;
+                    if (v > best) { best = v; best_i = o; }
+                }
+            }
+            // combine the four lanes (q = 0..3) that share a batch row
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                lp += __shfl_xor(lp, m);
+                const float ob = __shfl_xor(best, m);
+                const int oi = __shfl_xor(best_i, m);
+                const int oz = __shfl_xor((int)all_zero, m);
+                if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+                all_zero = all_zero && (oz != 0);
+            }
+            // resource share from component n (mappo_trainer.py:148-152): tanh in float64, result float32
+            const int src = c + 16 * (n >> 2);
+            const float raw = __shfl(act[0], src) * (float)((n & 3) == 0) + __shfl(act[1], src) * (float)((n & 3) == 1) +
+                              __shfl(act[2], src) * (float)((n & 3) == 2) + __shfl(act[3], src) * (float)((n & 3) == 3);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < O) a.ent_action[grow * O + 4 * q + r] = act[r];
+                if (q == 0) {
+                    a.ent_logp[grow] = a.explore ? lp : 0.0f;          // eval: log_prob = 0 (mappo_algorithm.py:218)
+                    const int place = all_zero ? 0 : best_i % n;
+                    double norm = (tanh((double)raw) + 1.0) / 2.0;
+                    norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
+                    a.placement[(int64_t)env * n + agent] = place;
+                    a.resource[(int64_t)env * n + agent] = (float)(0.1 + 0.9 * norm);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// trajectory indexing: exclusive scan of the per-environment acting-agent counts (one workgroup)
+// counters row t = {entry_base, n_entries, step_base, n_nonempty}; row t+1 bases are written here.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rollout_index_kernel(int64_t B, int t, const uint64_t* __restrict__ active,
+                                                             int64_t* __restrict__ counters, uint8_t* __restrict__ k_tb,
+                                                             int32_t* __restrict__ first_tb, int32_t* __restrict__ srow,
+                                                             int64_t cap_e, int64_t cap_s, int32_t* __restrict__ err)
+{
+    __shared__ unsigned long long wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
+    unsigned long long running = 0;   // low 32: entries, high 32: non-empty environments
+    for (int64_t p = 0; p < B; p += 1024) {
+        const int64_t b = p + tid;
+        const unsigned long long m = b < B ? active[b] : 0ull;
+        const unsigned long long k = (unsigned long long)__popcll(m);
+        const unsigned long long v = k | ((k ? 1ull : 0ull) << 32);
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned long long woff = 0, btot = 0;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv) {
+            const unsigned long long x = wave_tot[wv];
+            if (wv < wave) woff += x;
+            btot += x;
+        }
+        __syncthreads();
+        const unsigned long long excl = running + woff + inc - v;
+        if (b < B) {
+            k_tb[b] = (uint8_t)k;
+            first_tb[b] = (int32_t)(e_base + (int64_t)(excl & 0xffffffffull));
+            srow[b] = k ? (int32_t)(s_base + (int64_t)(excl >> 32)) : -1;
+        }
+        running += btot;
+    }
+    if (tid == 0) {
+        int64_t ne = (int64_t)(running & 0xffffffffull), ns = (int64_t)(running >> 32);
+        if (e_base + ne > cap_e || s_base + ns > cap_s) { atomicOr(err, 8); ne = 0; ns = 0; }
+        counters[4 * t + 1] = ne;
+        counters[4 * t + 3] = ns;
+        counters[4 * (t + 1) + 0] = e_base + ne;
+        counters[4 * (t + 1) + 2] = s_base + ns;
+    }
+}
+
+// one wavefront per environment: copies the dense state row block and the acting agents' rows
+__global__ __launch_bounds__(256) void rollout_compact_kernel(int64_t B, int n, int t, const float* __restrict__ obs,
+                                                              const int8_t* __restrict__ rank,
+                                                              const int64_t* __restrict__ counters,
+                                                              const uint8_t* __restrict__ k_tb,
+                                                              const int32_t* __restrict__ first_tb,
+                                                              const int32_t* __restrict__ srow, float* __restrict__ ent_obs,
+                                                              int32_t* __restrict__ ent_env, int8_t* __restrict__ ent_agent,
+                                                              float* __restrict__ st_state, int32_t* __restrict__ st_env,
+                                                              int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = n + 4, sw = n * w;
+    if (counters[4 * t + 1] == 0) return;     // nothing acted this step (or capacity overflow flagged)
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
+        const int k = k_tb[b];
+        if (k == 0) continue;
+        const int64_t first = first_tb[b], sr = srow[b];
+        const float* src = obs + b * sw;
+        for (int i = lane; i < sw; i += 64) {
+            const float v = src[i];
+            st_state[sr * sw + i] = v;
+            const int ag = i / w, col = i - ag * w;
+            const int r = rank[b * n + ag];
+            if (r >= 0) ent_obs[(first + r) * w + col] = v;
+        }
+        if (lane < n) {
+            const int r = rank[b * n + lane];
+            if (r >= 0) { ent_env[first + r] = (int32_t)b; ent_agent[first + r] = (int8_t)lane; }
+        }
+        if (lane == 0) { st_env[sr] = (int32_t)b; st_first[sr] = (int32_t)first; st_k[sr] = (uint8_t)k; }
+    }
+}
+
+int check_net(const em_mlp3* net)
+{
+    if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3)
+        return em::fail(EM_ERR_INVALID, "mlp3: null parameter pointer");
+    if (net->hidden != HID) return em::fail(EM_ERR_INVALID, "mlp3: hidden width must be %d", HID);
+    if (net->in_dim < 1 || net->in_dim > 144) return em::fail(EM_ERR_INVALID, "mlp3: in_dim must be 1..144");
+    if (net->out_dim < 1 || net->out_dim > 16) return em::fail(EM_ERR_INVALID, "mlp3: out_dim must be 1..16");
+    return EM_OK;
+}
+
+template <int MODE>
+int launch_fwd(const FwdArgs& fa, int64_t max_rows, hipStream_t s)
+{
+    const int ku = (fa.net.in_dim + 15) / 16;
+    int64_t tiles = (max_rows + 15) / 16;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;     // persistent: each wavefront keeps its weight fragments and strides over tiles
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(256);
+#define EM_FWD(KU_)                                                                                   \
+    case KU_: hipLaunchKernelGGL((mlp3_fwd_kernel<KU_, MODE>), grid, block, 0, s, fa); break
+    switch (ku) {
+        EM_FWD(1); EM_FWD(2); EM_FWD(3); EM_FWD(4); EM_FWD(5); EM_FWD(6); EM_FWD(7); EM_FWD(8); EM_FWD(9);
+        default: return em::fail(EM_ERR_INVALID, "mlp3: unsupported in_dim");
+    }
+#undef EM_FWD
+    return em::hip_check(hipGetLastError(), "mlp3_fwd_kernel launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+int em_mlp3_forward(const em_mlp3* net, const float* x, int64_t ldx, int64_t n_rows, float* y, void* stream)
+{
+    int rc = check_net(net);
+    if (rc) return rc;
+    if (!x || !y || n_rows < 0 || ldx < net->in_dim) return em::fail(EM_ERR_INVALID, "em_mlp3_forward: bad arguments");
+    if (n_rows == 0) return EM_OK;
+    FwdArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.net = *net; fa.x = x; fa.ldx = ldx; fa.n_rows = n_rows; fa.y = y;
+    return launch_fwd<0>(fa, n_rows, (hipStream_t)stream);
+}
+
+int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
+                     void* stream)
+{
+    if (!ro || !active || !rank || !obs) return em::fail(EM_ERR_INVALID, "em_rollout_index: null argument");
+    if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_rollout_index: step %d outside [0,%d)", t, ro->horizon);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t B = ro->n_envs;
+    hipLaunchKernelGGL(rollout_index_kernel, dim3(1), dim3(1024), 0, s, B, t, active, ro->counters, ro->k_tb + (int64_t)t * B,
+                       ro->first_tb + (int64_t)t * B, ro->srow, ro->capacity_entries, ro->capacity_steps, ro->err_flag);
+    int64_t blocks = (B + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rollout_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, B, ro->n_nodes, t, obs, rank,
+                       ro->counters, ro->k_tb + (int64_t)t * B, ro->first_tb + (int64_t)t * B, ro->srow, ro->ent_obs,
+                       ro->ent_env, ro->ent_agent, ro->st_state, ro->st_env, ro->st_first, ro->st_k);
+    return em::hip_check(hipGetLastError(), "rollout index/compact launch");
+}
+
+int em_policy_step(const em_rollout* ro, int32_t t, const em_mlp3* actor, const float* log_std, const em_mlp3* critic,
+                   float value_norm_mean, float value_norm_var, const float* noise, int explore, uint64_t seed,
+                   uint32_t episode, uint32_t rng_step, uint64_t env_offset, int32_t* placement, float* resource, void* stream)
+{
+    if (!ro || !placement || !resource || !log_std) return em::fail(EM_ERR_INVALID, "em_policy_step: null argument");
+    if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_policy_step: step outside the horizon");
+    int rc = check_net(actor);
+    if (rc) return rc;
+    rc = check_net(critic);
+    if (rc) return rc;
+    const int n = ro->n_nodes;
+    if (actor->in_dim != n + 4 || actor->out_dim != n + 1 || critic->in_dim != n * (n + 4) || critic->out_dim != 1)
+        return em::fail(EM_ERR_INVALID, "em_policy_step: network shapes do not match n_nodes=%d", n);
+    if (n + 1 > 16) return em::fail(EM_ERR_INVALID, "em_policy_step: n_nodes must be <= 15 for the fused policy epilogue");
+    hipStream_t s = (hipStream_t)stream;
+    FwdArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.net = *actor; fa.x = ro->ent_obs; fa.ldx = n + 4; fa.dyn = ro->counters + 4 * t;
+    fa.log_std = log_std; fa.noise = noise; fa.ent_action = ro->ent_action; fa.ent_logp = ro->ent_logp;
+    fa.ent_env = ro->ent_env; fa.ent_agent = ro->ent_agent; fa.placement = placement; fa.resource = resource;
+    fa.n_nodes = n; fa.explore = explore ? 1 : 0;
+    fa.seed_lo = (uint32_t)seed; fa.seed_hi = (uint32_t)(seed >> 32); fa.episode = episode; fa.step = rng_step;
+    fa.env_offset = (uint32_t)env_offset;
+    rc = launch_fwd<1>(fa, ro->n_envs * n, s);
+    if (rc) return rc;
+    FwdArgs fc;
+    std::memset(&fc, 0, sizeof fc);
+    fc.net = *critic; fc.x = ro->st_state; fc.ldx = (int64_t)n * (n + 4); fc.dyn = ro->counters + 4 * t + 2;
+    fc.st_value = ro->st_value; fc.st_env = ro->st_env; fc.value_tb = ro->value_tb + (int64_t)t * ro->n_envs;
+    fc.norm_mean = value_norm_mean; fc.norm_scale = sqrtf(value_norm_var + 1e-8f);
+    return launch_fwd<2>(fc, ro->n_envs, s);
+}
+
+}  // extern "C"

@@ -150,7 +150,10 @@ class BatchedEdgeSimGym:
                                         C.byref(self._out), _stream_ptr(self.device)), "em_reset")
         return self.obs, self.active
 
-    def step(self, placement: torch.Tensor, resource: torch.Tensor, tape: DeviceTape | None = None):
+    def step(self, placement: torch.Tensor, resource: torch.Tensor, tape: DeviceTape | None = None,
+             reward_seen_out: torch.Tensor | None = None, done_out: torch.Tensor | None = None):
+        """``reward_seen_out`` / ``done_out`` ([B] float64 / uint8, contiguous) redirect those two outputs of this
+        call, e.g. straight into a row of the rollout storage."""
         B, n = self.n_envs, self.n_nodes
         if placement.dtype != torch.int32 or resource.dtype != torch.float32:
             raise TypeError("placement must be int32 and resource float32")
@@ -160,10 +163,18 @@ class BatchedEdgeSimGym:
             raise ValueError("actions must live on the environment's device")
         if not (placement.is_contiguous() and resource.is_contiguous()):
             raise ValueError("actions must be contiguous")
-        with torch.cuda.device(self.device):
-            _lib.check(self._L.em_step(self._h, placement.data_ptr(), resource.data_ptr(),
-                                       C.byref(tape.struct) if tape is not None else None, C.byref(self._out),
-                                       _stream_ptr(self.device)), "em_step")
+        o = self._out
+        if reward_seen_out is not None:
+            o.reward_seen = reward_seen_out.data_ptr()
+        if done_out is not None:
+            o.done = done_out.data_ptr()
+        try:
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.em_step(self._h, placement.data_ptr(), resource.data_ptr(),
+                                           C.byref(tape.struct) if tape is not None else None, C.byref(o),
+                                           _stream_ptr(self.device)), "em_step")
+        finally:
+            o.reward_seen, o.done = self.reward.data_ptr(), self.done.data_ptr()
         info = {"reward_raw": self.reward_raw, "emitted": self.emitted, "rank": self.rank, "active": self.active}
         return self.obs, self.reward, self.done, self.truncated, info
 

@@ -1,0 +1,382 @@
+"""MAPPO on MI355X: the reference's ``mappo_algorithm.MAPPO`` surface (constructor arguments, attributes poked
+by ``run_mappo_batch.py:255-261``, ``update()``, ``save()/load()`` with the same checkpoint keys) over the HIP
+kernels of ``csrc/mappo_fwd.hip`` / ``csrc/mappo_bwd.hip``.  torch holds the device buffers (parameters are
+``nn.Parameter`` views of one flat float32 buffer so reference checkpoints load unchanged) and, for
+multi-GPU, runs the one gradient all-reduce over RCCL; no torch autograd, optimizer or nn.functional op is on
+the compute path."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+HID = 64
+
+
+def _stream(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _FlatNet(nn.Module):
+    """Parameter container with the reference's module/parameter names; compute goes through the C ABI."""
+
+    def _adopt(self, flat: torch.Tensor, names_shapes):
+        off = 0
+        self._slices = OrderedDict()
+        for name, shape in names_shapes:
+            n = int(torch.Size(shape).numel())
+            view = flat[off:off + n].view(shape)
+            mod_name, _, p_name = name.rpartition(".")
+            holder = self.get_submodule(mod_name) if mod_name else self
+            with torch.no_grad():
+                view.copy_(getattr(holder, p_name).detach().to(flat.device))
+            holder._parameters[p_name] = nn.Parameter(view, requires_grad=False)
+            self._slices[name] = (off, n)
+            off += n
+        self.flat = flat[:off]
+        return off
+
+    def mlp3(self, w1, w2, w3) -> _lib.EmMlp3:
+        return _lib.EmMlp3(w1.weight.data_ptr(), w1.bias.data_ptr(), w2.weight.data_ptr(), w2.bias.data_ptr(),
+                           w3.weight.data_ptr(), w3.bias.data_ptr(), w1.weight.shape[1], HID, w3.weight.shape[0])
+
+
+class MAPPOActor(_FlatNet):
+    """Shared actor 14->64->64->11 + state-independent log_std (mappo_algorithm.py:16-71)."""
+
+    def __init__(self, obs_dim, action_dim, hidden_dim=HID):
+        super().__init__()
+        if hidden_dim != HID:
+            raise ValueError("the MI355X kernels are built for hidden_dim=64")
+        self.fc1 = nn.Linear(obs_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.mu = nn.Linear(hidden_dim, action_dim)
+        self.log_std = nn.Parameter(torch.zeros(action_dim))
+        self.obs_dim, self.action_dim = obs_dim, action_dim
+
+    def adopt(self, flat):
+        return self._adopt(flat, [("fc1.weight", (HID, self.obs_dim)), ("fc1.bias", (HID,)), ("fc2.weight", (HID, HID)),
+                                  ("fc2.bias", (HID,)), ("mu.weight", (self.action_dim, HID)), ("mu.bias", (self.action_dim,)),
+                                  ("log_std", (self.action_dim,))])
+
+    def net(self):
+        return self.mlp3(self.fc1, self.fc2, self.mu)
+
+    def forward(self, obs):
+        return mlp3_forward(self.net(), obs)
+
+
+class MAPPOCritic(_FlatNet):
+    """Central critic 140->64->64->1 (mappo_algorithm.py:74-90)."""
+
+    def __init__(self, state_dim, hidden_dim=HID):
+        super().__init__()
+        if hidden_dim != HID:
+            raise ValueError("the MI355X kernels are built for hidden_dim=64")
+        self.fc1 = nn.Linear(state_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.value_out = nn.Linear(hidden_dim, 1)
+        self.state_dim = state_dim
+
+    def adopt(self, flat):
+        return self._adopt(flat, [("fc1.weight", (HID, self.state_dim)), ("fc1.bias", (HID,)), ("fc2.weight", (HID, HID)),
+                                  ("fc2.bias", (HID,)), ("value_out.weight", (1, HID)), ("value_out.bias", (1,))])
+
+    def net(self):
+        return self.mlp3(self.fc1, self.fc2, self.value_out)
+
+    def forward(self, state):
+        return mlp3_forward(self.net(), state)
+
+
+class ValueNormalizer(nn.Module):
+    """Buffers of the reference normaliser (mappo_algorithm.py:367-409).  Nothing in the reference ever calls
+    update(), so it stays the map x -> x / sqrt(1 + 1e-8); the kernels take mean/var as scalars."""
+
+    def __init__(self, input_shape, device="cpu"):
+        super().__init__()
+        self.register_buffer("running_mean", torch.zeros(input_shape, device=device))
+        self.register_buffer("running_var", torch.ones(input_shape, device=device))
+        self.register_buffer("count", torch.ones((), device=device))
+
+
+def mlp3_forward(net: _lib.EmMlp3, x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous().float()
+    rows = x.shape[0]
+    y = torch.empty((rows, net.out_dim), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().em_mlp3_forward(C.byref(net), x.data_ptr(), x.shape[1], rows, y.data_ptr(), _stream(x.device)),
+                   "em_mlp3_forward")
+    return y
+
+
+class HipAdam:
+    """State of torch.optim.Adam for one network on flat buffers; the update itself is em_adam_step.
+    ``param_groups[0]["lr"]`` can be overridden as run_mappo_batch.py:255-256 does; state_dict()/load_state_dict()
+    use torch.optim.Adam's layout (parameter order = module.parameters()) so checkpoints interchange."""
+
+    def __init__(self, module: _FlatNet, lr):
+        self.module = module
+        self.param_groups = [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                              "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                              "fused": None, "decoupled_weight_decay": False}]
+        self.exp_avg = torch.zeros_like(module.flat)
+        self.exp_avg_sq = torch.zeros_like(module.flat)
+        self.step_count = 0
+
+    def _torch_order(self):
+        return [name for name, _ in self.module.named_parameters()]
+
+    def state_dict(self):
+        names = self._torch_order()
+        state = {}
+        if self.step_count > 0:
+            for i, name in enumerate(names):
+                off, n = self.module._slices[name]
+                shape = dict(self.module.named_parameters())[name].shape
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
+        group = dict(self.param_groups[0])
+        group["params"] = list(range(len(names)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        names = self._torch_order()
+        g = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        self.step_count = 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, name in enumerate(names):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            off, n = self.module._slices[name]
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(float(st["step"]))
+
+
+class RolloutStorage:
+    """Device buffers of ``em_rollout`` for one batch of episodes (RolloutBuffer, mappo_algorithm.py:93-131)."""
+
+    def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None):
+        B, n, T = int(n_envs), int(n_nodes), int(horizon)
+        w, A = n + 4, n + 1
+        if capacity_steps is None:
+            capacity_steps = B * T
+        if capacity_entries is None:   # exact worst case for small batches, 2.2 acting agents per env-step otherwise
+            capacity_entries = B * T * n if B * T * n <= (1 << 22) else int(B * T * 2.2)
+        self.n_envs, self.n_nodes, self.horizon, self.device = B, n, T, device
+        self.capacity_entries, self.capacity_steps = int(capacity_entries), int(capacity_steps)
+        E, S = self.capacity_entries, self.capacity_steps
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        self.t = OrderedDict(
+            ent_obs=z((E, w), f32), ent_action=z((E, A), f32), ent_logp=z(E, f32), ent_env=z(E, i32),
+            ent_agent=z(E, torch.int8), ent_adv=z(E, f32), ent_ret=z(E, f32),
+            st_state=z((S, n * w), f32), st_value=z(S, f32), st_env=z(S, i32), st_first=z(S, i32), st_k=z(S, u8),
+            reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), value_tb=z((T, B), f32), k_tb=z((T, B), u8),
+            first_tb=z((T, B), i32), srow=z(B, i32), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32))
+        self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() for v in self.t.values()])
+        self.steps_recorded = 0
+
+    def clear(self):
+        self.t["counters"].zero_()
+        self.t["k_tb"].zero_()
+        self.steps_recorded = 0
+
+    def totals(self):
+        """(entries, steps) recorded so far; synchronises."""
+        c = self.t["counters"][self.steps_recorded].tolist()
+        if int(self.t["err_flag"].item()) != 0:
+            raise RuntimeError("rollout storage capacity exceeded; construct RolloutStorage with larger capacities")
+        return int(c[0]), int(c[2])
+
+    def __len__(self):
+        return self.totals()[0]
+
+
+class MAPPO:
+    """Same constructor as the reference (mappo_algorithm.py:145-160) plus ``n_envs``/``horizon`` for the
+    device rollout storage.  Hyper-parameter attributes can be overridden after construction."""
+
+    def __init__(self, obs_dim, state_dim, action_dim, n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
+                 value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4, device="cuda:0",
+                 n_envs=1, horizon=1000, process_group=None):
+        self.obs_dim, self.state_dim, self.action_dim, self.n_agents = obs_dim, state_dim, action_dim, n_agents
+        self.gamma, self.gae_lambda, self.clip_param = gamma, gae_lambda, clip_param
+        self.value_loss_coeff, self.entropy_coeff = value_loss_coeff, entropy_coeff
+        self.max_grad_norm, self.num_sgd_iter = max_grad_norm, num_sgd_iter
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("marl_amd.MAPPO runs on an MI355X (device='cuda:N'); there is no CPU path")
+        self.process_group = process_group
+        self._L = _lib.lib()
+        # same construction order as the reference (actor then critic, on the CPU generator) so that
+        # torch.manual_seed(seed) gives the reference's initial weights
+        self.actor = MAPPOActor(obs_dim, action_dim)
+        self.critic = MAPPOCritic(state_dim)
+        n_a = sum(p.numel() for p in self.actor.parameters())
+        n_c = sum(p.numel() for p in self.critic.parameters())
+        self.flat_params = torch.zeros(n_a + n_c, dtype=torch.float32, device=self.device)
+        assert self.actor.adopt(self.flat_params[:n_a]) == n_a and self.critic.adopt(self.flat_params[n_a:]) == n_c
+        self.n_actor, self.n_critic = n_a, n_c
+        self.flat_grads = torch.zeros(n_a + n_c + 8, dtype=torch.float32, device=self.device)   # + 2x3 loss sums
+        self.actor_optimizer = HipAdam(self.actor, lr)
+        self.critic_optimizer = HipAdam(self.critic, lr)
+        self.value_normalizer = ValueNormalizer(1, device=self.device)
+        self.buffer = RolloutStorage(n_envs, n_agents, horizon, self.device)
+        self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._gae_partials = torch.zeros(3 * ((n_envs + 255) // 256), dtype=torch.float64, device=self.device)
+        self._slab_a = self._slab_c = None
+        self.grad_norms = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.last_update = {}
+
+    # -- rollout side ----------------------------------------------------------------------------------
+    def _norm(self):
+        return float(self.value_normalizer.running_mean.reshape(-1)[0]), float(self.value_normalizer.running_var.reshape(-1)[0])
+
+    def record_and_act(self, t, obs, active, rank, placement_out, resource_out, explore=True, noise=None, seed=0,
+                       episode=0, env_offset=0, rng_step=None):
+        """Steps 199-219 of MAPPOTrainer.train_episode for all environments: index the acting agents, sample
+        their actions, format the env actions and evaluate the critic on the pre-step state."""
+        ro = self.buffer
+        with torch.cuda.device(self.device):
+            s = _stream(self.device)
+            _lib.check(self._L.em_rollout_index(C.byref(ro.struct), t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s),
+                       "em_rollout_index")
+            a_net, c_net = self.actor.net(), self.critic.net()
+            mean, var = self._norm_cached
+            _lib.check(self._L.em_policy_step(C.byref(ro.struct), t, C.byref(a_net), self.actor.log_std.data_ptr(),
+                                              C.byref(c_net), mean, var, noise.data_ptr() if noise is not None else None,
+                                              1 if explore else 0, int(seed) & (2**64 - 1), int(episode),
+                                              int(t if rng_step is None else rng_step), int(env_offset),
+                                              placement_out.data_ptr(), resource_out.data_ptr(), s), "em_policy_step")
+        ro.steps_recorded = t + 1
+
+    def begin_rollout(self):
+        self.buffer.clear()
+        self._norm_cached = self._norm()
+
+    # -- GAE (mappo_algorithm.py:241-262) --------------------------------------------------------------
+    def compute_gae(self):
+        ro = self.buffer
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_gae(C.byref(ro.struct), float(self.gamma), float(self.gae_lambda),
+                                      self._gae_partials.data_ptr(), self._gae_partials.numel(), self.moments.data_ptr(),
+                                      _stream(self.device)), "em_gae")
+
+    # -- update (mappo_algorithm.py:264-345) -----------------------------------------------------------
+    def _waves(self, rows):
+        tiles = (rows + 15) // 16
+        blocks = max(1, min(256, (tiles + 3) // 4))
+        return 4 * blocks
+
+    def update(self):
+        ro = self.buffer
+        if ro.steps_recorded == 0:
+            return {}
+        E, S = ro.totals()
+        if E == 0:
+            ro.clear()
+            return {}
+        dist = None
+        if self.process_group is not None:
+            import torch.distributed as dist  # noqa: F811
+        self.compute_gae()
+        n_global = E
+        if dist is not None:   # global advantage moments and transition count
+            dist.all_reduce(self.moments, group=self.process_group)
+            n_global = int(round(float(self.moments[0].item())))
+        L = self._L
+        na, nc = self.n_actor, self.n_critic
+        wa, wc = self._waves(E), self._waves(S)
+        sa = int(L.em_ppo_slab_floats(self.obs_dim, self.action_dim, 1))
+        sc = int(L.em_ppo_slab_floats(self.state_dim, 1, 0))
+        if self._slab_a is None or self._slab_a.numel() < wa * sa:
+            self._slab_a = torch.empty(wa * sa, dtype=torch.float32, device=self.device)
+        if self._slab_c is None or self._slab_c.numel() < wc * sc:
+            self._slab_c = torch.empty(wc * sc, dtype=torch.float32, device=self.device)
+        mean, var = self._norm()
+        g = self.flat_grads
+        loss_a, loss_c = g[na + nc:na + nc + 3], g[na + nc + 4:na + nc + 7]
+        t = ro.t
+        acc = torch.zeros(8, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            s = _stream(self.device)
+            for _ in range(int(self.num_sgd_iter)):
+                a_net, c_net = self.actor.net(), self.critic.net()
+                _lib.check(L.em_ppo_actor_grad(C.byref(a_net), self.actor.log_std.data_ptr(), t["ent_obs"].data_ptr(),
+                                               t["ent_action"].data_ptr(), t["ent_logp"].data_ptr(), t["ent_adv"].data_ptr(),
+                                               self.moments.data_ptr(), E, n_global, float(self.clip_param),
+                                               float(self.entropy_coeff), self._slab_a.data_ptr(), wa, g.data_ptr(),
+                                               loss_a.data_ptr(), s), "em_ppo_actor_grad")
+                _lib.check(L.em_ppo_critic_grad(C.byref(c_net), t["st_state"].data_ptr(), t["st_first"].data_ptr(),
+                                                t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
+                                                float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
+                                                g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
+                if dist is not None:   # the one data-path collective: flat gradient-of-sums + loss sums
+                    dist.all_reduce(g, group=self.process_group)
+                self.actor_optimizer.step_count += 1
+                self.critic_optimizer.step_count += 1
+                ga, gc = self.actor_optimizer.param_groups[0], self.critic_optimizer.param_groups[0]
+                _lib.check(L.em_adam_step(self.actor.flat.data_ptr(), g.data_ptr(), self.actor_optimizer.exp_avg.data_ptr(),
+                                          self.actor_optimizer.exp_avg_sq.data_ptr(), na, float(ga["lr"]),
+                                          self.critic.flat.data_ptr(), g[na:].data_ptr(),
+                                          self.critic_optimizer.exp_avg.data_ptr(), self.critic_optimizer.exp_avg_sq.data_ptr(),
+                                          nc, float(gc["lr"]), self.actor_optimizer.step_count, float(ga["betas"][0]),
+                                          float(ga["betas"][1]), float(ga["eps"]), float(self.max_grad_norm),
+                                          self.grad_norms.data_ptr(), s), "em_adam_step")
+                acc += g[na + nc:]          # per-epoch loss sums (already global after the all-reduce)
+        ro.clear()
+        sums = acc.cpu()
+        k = float(self.num_sgd_iter) * n_global
+        self.last_update = {"actor_loss": float(-sums[0] / k), "critic_loss": float(0.5 * sums[4] / k),
+                            "entropy": float(sums[1] / k), "transitions": n_global}
+        return {"actor_loss": self.last_update["actor_loss"], "critic_loss": self.last_update["critic_loss"],
+                "entropy": self.last_update["entropy"]}
+
+    # -- dict-API conveniences of the reference (mappo_algorithm.py:189-239), tiny batches ---------------------
+    def get_values(self, state):
+        x = torch.as_tensor(state, dtype=torch.float32, device=self.device).reshape(1, -1)
+        mean, var = self._norm()
+        return float(self.critic(x)[0, 0]) * math.sqrt(var + 1e-8) + mean
+
+    # -- checkpoint (mappo_algorithm.py:347-364): same keys and tensor names -----------------------------------
+    def save(self, path):
+        torch.save({"actor": {k: v.detach().cpu().clone() for k, v in self.actor.state_dict().items()},
+                    "critic": {k: v.detach().cpu().clone() for k, v in self.critic.state_dict().items()},
+                    "actor_optimizer": _cpu(self.actor_optimizer.state_dict()),
+                    "critic_optimizer": _cpu(self.critic_optimizer.state_dict()),
+                    "value_normalizer": {k: v.detach().cpu().clone() for k, v in self.value_normalizer.state_dict().items()}},
+                   path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        with torch.no_grad():
+            for mod, key in ((self.actor, "actor"), (self.critic, "critic")):
+                own = dict(mod.named_parameters())
+                for name, val in ck[key].items():
+                    own[name].copy_(val.to(self.device))
+        self.actor_optimizer.load_state_dict(ck["actor_optimizer"])
+        self.critic_optimizer.load_state_dict(ck["critic_optimizer"])
+        self.value_normalizer.load_state_dict({k: v.to(self.device) for k, v in ck["value_normalizer"].items()})
+
+
+def _cpu(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return {k: _cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_cpu(v) for v in obj)
+    return obj

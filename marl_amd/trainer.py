@@ -1,0 +1,161 @@
+"""MAPPOTrainer on MI355X: the reference trainer's interface (``mappo_trainer.py:23-394``: constructor,
+``train_episode``, ``train``, ``evaluate``, ``save_model/load_model``, ``run_mappo_experiment``) with a leading
+batch-of-environments dimension (``n_envs``).  One call of ``train_episode`` plays one episode in EVERY
+environment; ``trainer.mappo.update()`` then consumes the whole batch exactly as the reference consumes one
+episode buffer.  Multi-GPU: one process per GPU, environments sharded by rank, gradients all-reduced in
+``MAPPO.update`` (RCCL)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .config import ENV_CONFIG
+from .env import METRIC_KEYS, BatchedEdgeSimGym
+from .mappo import MAPPO, RolloutStorage
+
+_STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tps", "load_balance_jain")
+
+
+class MAPPOTrainer:
+    def __init__(self, env_config, seed=0, device="cuda:0", n_envs=1, rank=0, world_size=1, process_group=None,
+                 verbose=True):
+        if str(device) == "cuda":
+            device = "cuda:0"
+        self.device = torch.device(device)
+        self.seed, self.n_envs, self.rank, self.world_size = int(seed), int(n_envs), int(rank), int(world_size)
+        cfg = {**env_config}
+        self.env_offset = self.rank * self.n_envs
+        self.env = BatchedEdgeSimGym(cfg, n_envs=self.n_envs, device=self.device, seed=self.seed,
+                                     env_offset=self.env_offset)
+        # same seeding calls as the reference (mappo_trainer.py:43-46); torch's CPU generator then gives the
+        # reference's initial weights for this seed
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(seed)
+        self.n_agents = int(cfg["n_nodes"])
+        # the reference probes up to ten reseeded resets for a non-empty observation (mappo_trainer.py:53-58),
+        # which leaves the environment stream keyed by seed + attempt
+        for attempt in range(10):
+            _, active = self.env.reset(seed=self.seed + attempt)
+            if bool((active != 0).any()):
+                break
+        self.obs_dim = 5 + (self.n_agents - 1)
+        self.action_dim = self.n_agents + 1
+        self.state_dim = self.obs_dim * self.n_agents
+        self.mappo = MAPPO(obs_dim=self.obs_dim, state_dim=self.state_dim, action_dim=self.action_dim,
+                           n_agents=self.n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
+                           value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4,
+                           device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
+                           process_group=process_group)
+        B, n = self.n_envs, self.n_agents
+        self.placement = torch.zeros((B, n), dtype=torch.int32, device=self.device)
+        self.resource = torch.full((B, n), 0.5, dtype=torch.float32, device=self.device)
+        self._train_storage = self.mappo.buffer
+        self._scratch_storage = None
+        self.policy_episode = 0
+        if verbose and self.rank == 0:
+            print(f"[OK] MAPPO (MI355X) initialised: obs {self.obs_dim}, state {self.state_dim}, action {self.action_dim}, "
+                  f"agents {self.n_agents}, envs/GPU {self.n_envs}, device {self.device}")
+
+    # ------------------------------------------------------------------------------------------------------
+    def train_episode(self, explore=True, record_buffer=True, tapes=None, noise=None):
+        """One episode in every environment (mappo_trainer.py:177-250).  ``tapes`` (list of DeviceTape, one per
+        reset/step) and ``noise`` ([entries, action_dim] standard normal draws) replace the in-kernel random
+        streams for parity runs.  Returns the reference's stat keys (means over the environments) plus per-env
+        arrays under ``per_env``."""
+        env, m = self.env, self.mappo
+        T = env.episode_len
+        if record_buffer:
+            m.buffer = self._train_storage
+        else:   # evaluation episodes must not clobber a recorded batch (run_mappo_batch.py:272-317 evaluates first)
+            if self._scratch_storage is None:
+                self._scratch_storage = RolloutStorage(self.n_envs, self.n_agents, 1, self.device)
+            m.buffer = self._scratch_storage
+        ro = m.buffer
+        env.reset(tape=tapes[0] if tapes is not None else None)
+        m.begin_rollout()
+        self.policy_episode += 1
+        total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        try:
+            for t in range(T):
+                slot = t if record_buffer else 0
+                m.record_and_act(slot, env.obs, env.active, env.rank, self.placement, self.resource, explore=explore,
+                                 noise=noise, seed=self.seed, episode=self.policy_episode, env_offset=self.env_offset,
+                                 rng_step=t)
+                if record_buffer:
+                    env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None,
+                             reward_seen_out=ro.t["reward_tb"][t], done_out=ro.t["done_tb"][t])
+                else:
+                    env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None)
+                    total_reward += env.reward
+        finally:
+            m.buffer = self._train_storage
+        if record_buffer:
+            total_reward = ro.t["reward_tb"].sum(dim=0)
+        metrics = env.episode_metrics()                      # [B, 6] on the device
+        # the reference harvests the metrics only when the final step produced observations
+        # (mappo_trainer.py:222-231), otherwise it reports 0.0 for all of them
+        has_final = (env.active != 0).to(torch.float64).unsqueeze(1)
+        per_env = torch.nan_to_num(metrics, nan=0.0) * has_final
+        mean = per_env.mean(dim=0).cpu().numpy()
+        idx = {k: i for i, k in enumerate(METRIC_KEYS)}
+        stats = {"episode_reward": float(total_reward.mean().item()), "episode_steps": T}
+        for k in _STAT_KEYS:
+            stats[k] = float(mean[idx[k]])
+        stats["per_env"] = {"episode_reward": total_reward, "metrics": metrics}
+        return stats
+
+    def train(self, num_iterations=1000, update_interval=1, eval_interval=10, eval_episodes=10, max_total_steps=5_000_000):
+        """mappo_trainer.py:252-316.  ``timestep`` counts environment steps of ONE environment (the reference's
+        unit); the batch plays n_envs x world_size times as many."""
+        if update_interval != 1:
+            raise NotImplementedError("the device rollout storage holds one episode batch: update_interval must be 1")
+        results_log, total_steps, iteration = [], 0, 0
+        while True:
+            iteration += 1
+            episode_stats = self.train_episode(explore=True, record_buffer=True)
+            total_steps += episode_stats["episode_steps"]
+            self.mappo.update()
+            if iteration % eval_interval == 0:
+                eval_stats = self.evaluate(num_episodes=eval_episodes)
+                entry = {"algorithm": "MAPPO", "seed": self.seed, "iteration": iteration, "timestep": total_steps,
+                         "episode_return_mean": episode_stats["episode_reward"]}
+                entry.update({k: eval_stats[k] for k in _STAT_KEYS})
+                results_log.append(entry)
+                if self.rank == 0:
+                    print(f"Iter {iteration}/{num_iterations} | Steps: {total_steps} | "
+                          f"Reward: {episode_stats['episode_reward']:.2f} | Latency: {eval_stats['avg_latency_ms']:.2f}ms")
+            if total_steps >= max_total_steps:
+                break
+        return results_log
+
+    def evaluate(self, num_episodes=100):
+        """mappo_trainer.py:318-351: deterministic policy, environment exploration disabled.  Each call of
+        train_episode already plays n_envs episodes, so ceil(num_episodes / n_envs) batches are run."""
+        prev = self.env.disable_env_exploration
+        self.env.disable_env_exploration = True
+        acc = {k: [] for k in _STAT_KEYS}
+        try:
+            for _ in range(max(1, -(-int(num_episodes) // self.n_envs))):
+                stats = self.train_episode(explore=False, record_buffer=False)
+                for k in _STAT_KEYS:
+                    acc[k].append(stats[k])
+        finally:
+            self.env.disable_env_exploration = prev
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+    def save_model(self, path):
+        self.mappo.save(path)
+
+    def load_model(self, path):
+        self.mappo.load(path)
+
+
+def run_mappo_experiment(seed, num_iterations=1000, max_total_steps=5_000_000, n_envs=1, device="cuda:0"):
+    """mappo_trainer.py:364-394."""
+    trainer = MAPPOTrainer(ENV_CONFIG, seed=seed, device=device, n_envs=n_envs)
+    log = trainer.train(num_iterations=num_iterations, update_interval=1, eval_interval=10, eval_episodes=10,
+                        max_total_steps=max_total_steps)
+    trainer.save_model(f"mappo_seed_{seed}.pt")
+    return log
