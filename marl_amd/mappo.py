@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .parallel import GradSync
 
 HID = 64
 
@@ -220,6 +221,7 @@ class MAPPO:
         if self.device.type != "cuda":
             raise RuntimeError("marl_amd.MAPPO runs on an MI355X (device='cuda:N'); there is no CPU path")
         self.process_group = process_group
+        self.sync = GradSync(process_group)
         self._L = _lib.lib()
         # same construction order as the reference (actor then critic, on the CPU generator) so that
         # torch.manual_seed(seed) gives the reference's initial weights
@@ -289,14 +291,8 @@ class MAPPO:
         if E == 0:
             ro.clear()
             return {}
-        dist = None
-        if self.process_group is not None:
-            import torch.distributed as dist  # noqa: F811
         self.compute_gae()
-        n_global = E
-        if dist is not None:   # global advantage moments and transition count
-            dist.all_reduce(self.moments, group=self.process_group)
-            n_global = int(round(float(self.moments[0].item())))
+        n_global = self.sync.sum_moments(self.moments)   # global advantage moments and transition count
         L = self._L
         na, nc = self.n_actor, self.n_critic
         wa, wc = self._waves(E), self._waves(S)
@@ -324,8 +320,7 @@ class MAPPO:
                                                 t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
                                                 float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
                                                 g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
-                if dist is not None:   # the one data-path collective: flat gradient-of-sums + loss sums
-                    dist.all_reduce(g, group=self.process_group)
+                self.sync.sum_grads(g)   # the one data-path collective per epoch: gradient-of-sums + loss sums
                 self.actor_optimizer.step_count += 1
                 self.critic_optimizer.step_count += 1
                 ga, gc = self.actor_optimizer.param_groups[0], self.critic_optimizer.param_groups[0]

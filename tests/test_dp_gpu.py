@@ -1,0 +1,51 @@
+"""Two ranks (gloo over CUDA tensors, both on the box's single GPU) against one process on the union of the
+environments: same Philox streams per global environment, so trajectories are identical and the parameters
+after k updates agree to fp32 summation-order noise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+T, B_TOTAL, UPDATES = 60, 12, 2
+
+
+def _cfg():
+    from marl_amd.config import ENV_CONFIG
+    cfg = dict(ENV_CONFIG)
+    cfg["episode_length"] = T
+    return cfg
+
+
+def _run(trainer):
+    for _ in range(UPDATES):
+        trainer.train_episode(explore=True, record_buffer=True)
+        trainer.mappo.update()
+    return trainer.mappo.flat_params.detach().cpu().numpy().copy()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=B_TOTAL // world, rank=rank, world_size=world, verbose=False)
+    np.save(os.path.join(out_dir, f"params_{rank}.npy"), _run(tr))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_one_process(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = (np.load(tmp_path / f"params_{r}.npy") for r in range(2))
+    assert np.array_equal(p0, p1)
+    from marl_amd.trainer import MAPPOTrainer
+    single = _run(MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=B_TOTAL, verbose=False))
+    np.testing.assert_allclose(p0, single, rtol=2e-4, atol=2e-6)
