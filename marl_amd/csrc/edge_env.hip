@@ -62,8 +62,10 @@ __device__ inline uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per half round (v_mad_u64_u32) instead of separate hi/lo multiplies
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0;
+        const uint32_t hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -149,6 +151,13 @@ __device__ inline double np_sum_small(const double* a, int n)
     return 0.0 + res;
 }
 
+// Lane-parallel pre-draw of the environment-level random numbers: lane 0 of an environment's group
+// evaluates the P_DT block, lanes 1..3 the first three P_POIS blocks (six uniforms of the Knuth
+// loop), lanes 4..9 P_TASK_A and lanes 10..15 P_TASK_B of the first six arrivals.  Later Poisson
+// uniforms / arrivals (rare) are evaluated inline by the group.  The stream is counter addressed,
+// so this is bit-identical to drawing them one after the other (oracle/edge_oracle.c does that).
+enum { PRE_LANES = 16, PRE_POIS_U = 6, PRE_TASKS = 6 };
+
 template <int LPE>
 __device__ inline uint64_t group_bits(uint64_t ballot, int g)
 {
@@ -202,6 +211,13 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     double* s_en = reinterpret_cast<double*>(wbase + off) + g * n;
     off += EPW * n * 8;
     float* s_ratio = reinterpret_cast<float*>(wbase + off) + g * n;
+    off += (EPW * n * 4 + 7) & ~7;
+    // environment-level draws of the step, produced by one Philox block per lane (philox mode only)
+    double* s_ra = reinterpret_cast<double*>(wbase + off) + g * PRE_LANES;
+    off += EPW * PRE_LANES * 8;
+    double* s_rb = reinterpret_cast<double*>(wbase + off) + g * PRE_LANES;
+    off += EPW * PRE_LANES * 8;
+    int32_t* s_rz = reinterpret_cast<int32_t*>(wbase + off) + g * PRE_LANES;
 
     // ---- stage in: records (or zeros at reset), zeroed observation tile, capacity table ---------
     {
@@ -354,9 +370,24 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     }
     double rate_u = 0.0, dt_u = 0.0;
     if constexpr (!TAPE) {
-        const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_DT << 24), p.seed_lo, p.seed_hi);
-        dt_u = u53(b.x, b.y);
-        rate_u = p.rate_lo + (p.rate_hi - p.rate_lo) * u53(b.z, b.w);
+        if (sl < PRE_LANES) {
+            const bool is_dt = sl == 0, is_pois = sl >= 1 && sl < 4, is_a = sl >= 4 && sl < 10;
+            const uint32_t purpose = is_dt ? P_DT : (is_pois ? P_POIS : (is_a ? P_TASK_A : P_TASK_B));
+            const uint32_t index = is_dt ? 0u : (uint32_t)(is_pois ? sl - 1 : (is_a ? sl - 4 : sl - 10));
+            const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (purpose << 24) | index, p.seed_lo, p.seed_hi);
+            // value = lo + span * u; (lo, span) = (0, 1) leaves a raw uniform unchanged, bit for bit
+            const double lo_a = is_dt || is_pois ? 0.0 : (is_a ? p.wl_lo : p.ddl_lo);
+            const double sp_a = is_dt || is_pois ? 1.0 : (is_a ? p.wl_hi - p.wl_lo : p.ddl_hi - p.ddl_lo);
+            const double lo_b = is_dt ? p.rate_lo : (is_a ? p.data_lo : 0.0);
+            const double sp_b = is_dt ? p.rate_hi - p.rate_lo : (is_a ? p.data_hi - p.data_lo : 1.0);
+            s_ra[sl] = lo_a + sp_a * u53(b.x, b.y);
+            s_rb[sl] = lo_b + sp_b * u53(b.z, b.w);
+            s_rz[sl] = (int32_t)__umulhi(b.z, (uint32_t)n);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dt_u = s_ra[0];
+        rate_u = s_rb[0];
     }
     double rate;
     if (p.rate_lo == p.rate_hi) rate = p.rate_lo;
@@ -389,12 +420,22 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     } else if (valid) {
         const double limit = det_exp(-(rate_c * window));
         double prod = 1.0;
-        uint4 b = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = 0;; ++i) {   // Knuth multiplication method; ends at n_new == 4096 at the latest
-            if ((i & 1u) == 0u) b = philox(envid, p.episode, (uint32_t)step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
-            const double u = (i & 1u) ? u53(b.z, b.w) : u53(b.x, b.y);
+        bool going = true;
+#pragma unroll
+        for (int i = 0; i < PRE_POIS_U; ++i) {   // Knuth multiplication method on the pre-drawn uniforms
+            const double u = (i & 1) ? s_rb[1 + (i >> 1)] : s_ra[1 + (i >> 1)];
             prod = prod * u;
-            if (prod > limit && n_new < 4096) ++n_new; else break;
+            going = going && prod > limit;
+            n_new += going ? 1 : 0;
+        }
+        if (going) {
+            uint4 b = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = PRE_POIS_U;; ++i) {   // rare tail; ends at n_new == 4096 at the latest
+                if ((i & 1u) == 0u) b = philox(envid, p.episode, (uint32_t)step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
+                const double u = (i & 1u) ? u53(b.z, b.w) : u53(b.x, b.y);
+                prod = prod * u;
+                if (prod > limit && n_new < 4096) ++n_new; else break;
+            }
         }
     }
     draws_env += 1;
@@ -412,6 +453,8 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
                 wl = tape.task_workload[o]; data = tape.task_data[o];
                 offs = tape.task_deadline_offset[o]; dec = tape.task_decider[o];
                 if (dec < 0 || dec >= n) { atomicOr(err_flag, 4); dec = 0; }
+            } else if (j < PRE_TASKS) {
+                wl = s_ra[4 + j]; data = s_rb[4 + j]; offs = s_ra[10 + j]; dec = s_rz[10 + j];
             } else {
                 const uint4 a = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_A << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
                 const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_B << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
@@ -615,7 +658,8 @@ EnvParams make_params(const em_handle* h, int lanes)
     wb += (epw * p.obs_floats * 4 + 15) & ~15;
     wb += p.n * 8;                 // capacities
     wb += 2 * epw * p.n * 8;       // latencies, energies of the step
-    wb += epw * p.n * 4;           // load ratios
+    wb += (epw * p.n * 4 + 7) & ~7;   // load ratios
+    wb += epw * PRE_LANES * 20;    // pre-drawn environment-level random numbers
     p.wave_bytes = (wb + 15) & ~15;
     p.rate_lo = c.arrival_rate_lo; p.rate_hi = c.arrival_rate_hi; p.cycle = c.arrival_cycle_seconds;
     p.wl_lo = c.workload_lo; p.wl_hi = c.workload_hi;
