@@ -28,6 +28,15 @@
 
 #pragma clang fp contract(off)
 
+// Optional in-kernel cycle stamps of workgroup 0 / lane 0 (tools/stamp_env.hip builds this file with
+// -DEM_STAMP); compiled out of the library.
+#ifdef EM_STAMP
+__device__ unsigned long long em_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) em_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -43,15 +52,42 @@ __host__ __device__ inline int rec_bytes(int n) { return (37 * n + 56 + 15) & ~1
 enum { I_STEP = 0, I_TASKS, I_VIOL, I_DONE, I_PENDING, I_LOGGED };
 enum { S_TIME = 0, S_ELAPSED, S_SUMLAT, S_SUMEN };
 
+// Per-launch scalars (kernel argument, SGPRs).
 struct EnvParams {
     int32_t n, horizon, rate_mode, explore;
     int32_t rec_bytes, obs_floats, wave_bytes, pad0;
-    double rate_lo, rate_hi, cycle;
-    double wl_lo, wl_hi, data_lo, data_hi, ddl_lo, ddl_hi, bw_lo, bw_hi, lat_lo, lat_hi;
-    double w_lat, w_en, w_viol, dt_min, dt_max, window0, eps;
+    double eps;
     uint32_t seed_lo, seed_hi, episode, env_offset;
     int64_t n_envs, lat_cap;
 };
+
+// Per-handle constants, resident in HBM (read with scalar loads where they are used, which keeps them
+// out of the kernel's long-lived SGPRs).  inv_* are correctly rounded reciprocals computed on the host:
+// a quotient by one of these constants is formed as q0 = x*inv; q = fma(fma(-q0, d, x), inv, q0), the
+// final steps of the hardware's own float64 division sequence (v_div_fmas after the residual), which is
+// correctly rounded for the value ranges of the simulator (tests/test_env_gpu.py::test_const_division).
+struct EnvConst {
+    double rate_lo, rate_span, rate_mid, cycle, inv_cycle;
+    double wl_lo, wl_span, data_lo, data_span, ddl_lo, ddl_span, bw_lo, bw_span, lat_lo, lat_span;
+    double w_lat, w_en, w_viol, dt_min, dt_max, window0;
+    double cap[EM_MAX_NODES], inv_cap[EM_MAX_NODES], inv_k[EM_MAX_NODES + 1];
+};
+
+__device__ inline double qdiv(double x, double d, double inv)
+{
+    const double q0 = x * inv;
+    return __builtin_fma(__builtin_fma(-q0, d, x), inv, q0);
+}
+
+// fmod(t, c) for t >= 0, c > 0: the remainder is exactly representable, so one fused residual is exact.
+__device__ inline double exact_fmod_pos(double t, double c, double inv_c)
+{
+    const double q = floor(t * inv_c);
+    double r = __builtin_fma(-q, c, t);
+    if (r < 0.0) r += c;
+    else if (r >= c) r -= c;
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and deterministic float64 helpers
@@ -169,8 +205,8 @@ __device__ inline uint64_t group_bits(uint64_t ballot, int g)
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int LPE, bool TAPE, bool RESET>
-__global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
-                                                  const double* __restrict__ cap_dev,
+__global__ __launch_bounds__(256, 6) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
+                                                  const EnvConst* __restrict__ cc,
                                                   const int32_t* __restrict__ placement,
                                                   const float* __restrict__ resource, const em_tape tape,
                                                   const em_step_out out, double* __restrict__ lat_log,
@@ -204,8 +240,10 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     float* s_obs_w = reinterpret_cast<float*>(wbase + off);
     float* s_obs = s_obs_w + g * p.obs_floats;
     off += (EPW * p.obs_floats * 4 + 15) & ~15;
-    double* s_cap = reinterpret_cast<double*>(wbase + off);
-    off += n * 8;
+    double* s_cap = reinterpret_cast<double*>(wbase + off);      // capacity, 1/capacity, 1/k tables
+    double* s_icap = s_cap + n;
+    double* s_ik = s_icap + n;
+    off += (3 * n + 1) * 8;
     double* s_lat = reinterpret_cast<double*>(wbase + off) + g * n;
     off += EPW * n * 8;
     double* s_en = reinterpret_cast<double*>(wbase + off) + g * n;
@@ -219,6 +257,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     off += EPW * PRE_LANES * 8;
     int32_t* s_rz = reinterpret_cast<int32_t*>(wbase + off) + g * PRE_LANES;
 
+    // the step's actions do not depend on the staged record: issue their loads first
+    int tgt_in = -1;
+    float res_in = 1.0f;
+    if constexpr (!RESET) {
+        if (agent) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+    }
+
+    STAMP(0);
     // ---- stage in: records (or zeros at reset), zeroed observation tile, capacity table ---------
     {
         uint4* dst = reinterpret_cast<uint4*>(wbase);
@@ -231,12 +277,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
         }
         uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
         for (int i = lane; i < ((EPW * p.obs_floats * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < n; i += 64) s_cap[i] = cap_dev[i];
+        for (int i = lane; i < n; i += 64) { s_cap[i] = cc->cap[i]; s_icap[i] = cc->inv_cap[i]; }
+        for (int i = lane; i <= n; i += 64) s_ik[i] = cc->inv_k[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const double cap_me = agent ? s_cap[sl] : 1.0;
+    const double icap_me = agent ? s_icap[sl] : 1.0;
     const uint32_t envid = p.env_offset + (uint32_t)env;
     const int step_no = RESET ? 0 : r_int[I_STEP] + 1;
     const double t_now = RESET ? 0.0 : r_scal[S_TIME];
@@ -245,11 +293,12 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     double reward = 0.0;
 
     if constexpr (!RESET) {
+        STAMP(1);
         // ---- placement phase: per-agent quantities in parallel on the lanes (MRRL.PY:397-423) ----
         int rank = agent ? (int)r_rank[sl] : -1;
-        int tgt = agent ? placement[env * n + sl] : -1;
+        int tgt = tgt_in;
         bool acting = rank >= 0 && tgt >= 0 && tgt < n;
-        float res = acting ? resource[env * n + sl] : 1.0f;
+        float res = acting ? res_in : 1.0f;
         const double wl = acting ? r_wl[sl] : 1.0;
         const double data = acting ? r_data[sl] : 1.0;
         const double ddl = acting ? r_ddl[sl] : 0.0;
@@ -296,20 +345,22 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
             if constexpr (TAPE) { bw_u = tape.bw_u[env * n + slot]; nlat = tape.net_lat[env * n + slot]; }
             else {
                 const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_NET << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
-                bw_u = p.bw_lo + (p.bw_hi - p.bw_lo) * u53(b.x, b.y);
-                nlat = p.lat_lo + (p.lat_hi - p.lat_lo) * u53(b.z, b.w);
+                bw_u = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
+                nlat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
             }
             draws_lane += 2;
             const double bw = bw_u * 1e6 / 8;
             t_trans = (data / bw) + nlat;
         }
         const double cap_t = acting ? s_cap[tgt] : 1.0;
+        const double icap_t = acting ? s_icap[tgt] : 1.0;
         const double alloc = cap_t * (double)res;        // MRRL.PY:418 (float64 * float32)
-        const double gcyc = alloc / 1e9;
+        const double gcyc = qdiv(alloc, 1e9, 1e-9);
         const double t_exec = wl / gcyc;                  // MRRL.PY:419
         const double energy = wl * gcyc;                  // MRRL.PY:423
         const double inc = t_exec * gcyc;                 // MRRL.PY:437
 
+        STAMP(2);
         // ---- ordered chain over arrival rank: queueing delay sees earlier placements (MRRL.PY:416,437)
         int k = 0;
         bool viol = false;
@@ -319,7 +370,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
             const uint64_t bal = __ballot(mine);
             if (mine) {
                 const double l = r_load[tgt];
-                const double t_queue = l / cap_t;
+                const double t_queue = qdiv(l, cap_t, icap_t);
                 const double t_total = t_trans + t_queue + t_exec;
                 viol = (t_now + t_total) > ddl;          // MRRL.PY:431
                 s_lat[k] = t_total;
@@ -333,10 +384,12 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
         const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g));
         __builtin_amdgcn_wave_barrier();
 
+        STAMP(3);
         // ---- reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466) ----------------
         if (k > 0) {
-            const double cost = (p.w_lat * (np_sum_small(s_lat, k) / (double)k)) +
-                                (p.w_en * (np_sum_small(s_en, k) / (double)k)) + (p.w_viol * (double)n_viol);
+            const double kd = (double)k, ik = s_ik[k];
+            const double cost = (cc->w_lat * qdiv(np_sum_small(s_lat, k), kd, ik)) +
+                                (cc->w_en * qdiv(np_sum_small(s_en, k), kd, ik)) + (cc->w_viol * (double)n_viol);
             reward = -cost;
         }
         const int tasks_before = r_int[I_TASKS];
@@ -363,10 +416,11 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
         __builtin_amdgcn_wave_barrier();
     }
 
+    STAMP(4);
     // ---- arrivals (MRRL.PY:340-383) ----------------------------------------------------------------
     if (agent) {
         r_rank[sl] = -1;
-        s_ratio[sl] = (float)(r_load[sl] / cap_me);      // load/cap BEFORE this step's decay
+        s_ratio[sl] = (float)qdiv(r_load[sl], cap_me, icap_me);   // load/cap BEFORE this step's decay
     }
     double rate_u = 0.0, dt_u = 0.0;
     if constexpr (!TAPE) {
@@ -376,10 +430,10 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
             const uint32_t index = is_dt ? 0u : (uint32_t)(is_pois ? sl - 1 : (is_a ? sl - 4 : sl - 10));
             const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (purpose << 24) | index, p.seed_lo, p.seed_hi);
             // value = lo + span * u; (lo, span) = (0, 1) leaves a raw uniform unchanged, bit for bit
-            const double lo_a = is_dt || is_pois ? 0.0 : (is_a ? p.wl_lo : p.ddl_lo);
-            const double sp_a = is_dt || is_pois ? 1.0 : (is_a ? p.wl_hi - p.wl_lo : p.ddl_hi - p.ddl_lo);
-            const double lo_b = is_dt ? p.rate_lo : (is_a ? p.data_lo : 0.0);
-            const double sp_b = is_dt ? p.rate_hi - p.rate_lo : (is_a ? p.data_hi - p.data_lo : 1.0);
+            const double lo_a = is_dt || is_pois ? 0.0 : (is_a ? cc->wl_lo : cc->ddl_lo);
+            const double sp_a = is_dt || is_pois ? 1.0 : (is_a ? cc->wl_span : cc->ddl_span);
+            const double lo_b = is_dt ? cc->rate_lo : (is_a ? cc->data_lo : 0.0);
+            const double sp_b = is_dt ? cc->rate_span : (is_a ? cc->data_span : 1.0);
             s_ra[sl] = lo_a + sp_a * u53(b.x, b.y);
             s_rb[sl] = lo_b + sp_b * u53(b.z, b.w);
             s_rz[sl] = (int32_t)__umulhi(b.z, (uint32_t)n);
@@ -389,30 +443,34 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
         dt_u = s_ra[0];
         rate_u = s_rb[0];
     }
+    STAMP(5);
     double rate;
-    if (p.rate_lo == p.rate_hi) rate = p.rate_lo;
+    if (p.rate_mode == 3) rate = cc->rate_lo;      // degenerate range (MRRL.PY:222-223)
     else if (p.rate_mode == 1) {
-        const double cyc = p.cycle > 1e-6 ? p.cycle : 1e-6;
-        const double phase = fmod(t_now, cyc) / cyc;
+        const double cyc = cc->cycle, icyc = cc->inv_cycle;   // cycle already clamped to >= 1e-6 (MRRL.PY:226)
+        const double phase = qdiv(exact_fmod_pos(t_now, cyc, icyc), cyc, icyc);
         // tape mode never uses the rate (dt and the arrival count come pre-drawn)
-        rate = p.rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * (p.rate_hi - p.rate_lo);
+        rate = cc->rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * cc->rate_span;
     } else if (p.rate_mode == 2) {
         if constexpr (TAPE) rate_u = valid ? tape.rate_u[env] : 0.0;
         rate = rate_u;
         draws_env += 1;
-    } else rate = 0.5 * (p.rate_lo + p.rate_hi);
+    } else rate = cc->rate_mid;
     const double rate_c = rate > 1e-6 ? rate : 1e-6;
 
+    STAMP(6);
     double window;
-    if constexpr (RESET) window = p.window0;
+    if constexpr (RESET) window = cc->window0;
     else {
         double raw;
         if constexpr (TAPE) raw = valid ? tape.dt_raw[env] : 0.0;
         else raw = (1.0 / rate_c) * (-det_log(1.0 - dt_u));
         draws_env += 1;
-        window = raw < p.dt_min ? p.dt_min : (raw > p.dt_max ? p.dt_max : raw);   // MRRL.PY:247
+        const double dt_min = cc->dt_min, dt_max = cc->dt_max;
+        window = raw < dt_min ? dt_min : (raw > dt_max ? dt_max : raw);   // MRRL.PY:247
     }
 
+    STAMP(7);
     int n_new = 0;
     if constexpr (TAPE) {
         n_new = valid ? tape.n_arrivals[env] : 0;
@@ -441,6 +499,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     draws_env += 1;
     __builtin_amdgcn_wave_barrier();
 
+    STAMP(8);
     int n_pending = 0;
     for (int j = 0;; ++j) {
         const bool more = j < n_new;
@@ -458,9 +517,9 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
             } else {
                 const uint4 a = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_A << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
                 const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_B << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
-                wl = p.wl_lo + (p.wl_hi - p.wl_lo) * u53(a.x, a.y);
-                data = p.data_lo + (p.data_hi - p.data_lo) * u53(a.z, a.w);
-                offs = p.ddl_lo + (p.ddl_hi - p.ddl_lo) * u53(b.x, b.y);
+                wl = cc->wl_lo + cc->wl_span * u53(a.x, a.y);
+                data = cc->data_lo + cc->data_span * u53(a.z, a.w);
+                offs = cc->ddl_lo + cc->ddl_span * u53(b.x, b.y);
                 dec = (int)__umulhi(b.z, (uint32_t)n);
             }
             draws_env += 4;
@@ -491,6 +550,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
         __builtin_amdgcn_wave_barrier();
     }
 
+    STAMP(9);
     // ---- decay, clock, outputs (MRRL.PY:364-375,444-459) --------------------------------------------
     if constexpr (!RESET) {
         if (agent) {
@@ -524,6 +584,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    STAMP(10);
     // ---- stage out: records and observation tile, 16-byte lane-linear stores -------------------------
     {
         const uint4* src = reinterpret_cast<const uint4*>(wbase);
@@ -541,13 +602,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvParams p, unsigned ch
             for (int i = lane; i < nfl; i += 64) gobs[i] = s_obs_w[i];
         }
     }
+    STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------
 // episode metrics (MRRL.PY:470-504); p99 from the latency log when present
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void metrics_kernel(const EnvParams p, const unsigned char* __restrict__ state,
-                                                      const double* __restrict__ cap_dev,
+                                                      const EnvConst* __restrict__ cc,
                                                       const double* __restrict__ lat_log, double* __restrict__ scratch,
                                                       double* __restrict__ out6)
 {
@@ -606,7 +668,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const EnvParams p, const u
         const double samples = (double)(ri[I_STEP] + 1);
         double s1 = 0.0, s2 = 0.0;
         for (int i = 0; i < n; ++i) {
-            const double m_i = (cap_dev[i] * el / (cap_dev[i] + 1e-9)) / samples;
+            const double m_i = (cc->cap[i] * el / (cc->cap[i] + 1e-9)) / samples;
             s1 += m_i;
             s2 += m_i * m_i;
         }
@@ -631,7 +693,7 @@ struct em_handle {
     int lanes = 0;                 // lanes per environment in use
     int lanes_forced = 0;
     unsigned char* d_state = nullptr;
-    double* d_cap = nullptr;
+    EnvConst* d_const = nullptr;
     double* d_lat_log = nullptr;
     double* d_sort_scratch = nullptr;
     int32_t* d_err = nullptr;
@@ -642,6 +704,31 @@ namespace {
 
 int pick_lanes(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
 
+EnvConst make_const(const em_config& c)
+{
+    EnvConst k;
+    std::memset(&k, 0, sizeof k);
+    k.rate_lo = c.arrival_rate_lo; k.rate_span = c.arrival_rate_hi - c.arrival_rate_lo;
+    k.rate_mid = 0.5 * (c.arrival_rate_lo + c.arrival_rate_hi);
+    k.cycle = c.arrival_cycle_seconds > 1e-6 ? c.arrival_cycle_seconds : 1e-6;
+    k.inv_cycle = 1.0 / k.cycle;
+    k.wl_lo = c.workload_lo; k.wl_span = c.workload_hi - c.workload_lo;
+    k.data_lo = c.data_lo; k.data_span = c.data_hi - c.data_lo;
+    k.ddl_lo = c.deadline_lo; k.ddl_span = c.deadline_hi - c.deadline_lo;
+    k.bw_lo = c.bw_lo; k.bw_span = c.bw_hi - c.bw_lo;
+    k.lat_lo = c.net_latency_lo; k.lat_span = c.net_latency_hi - c.net_latency_lo;
+    k.w_lat = c.w_latency; k.w_en = c.w_energy; k.w_viol = c.w_violation;
+    k.dt_min = c.min_time_step; k.dt_max = c.max_time_step; k.window0 = c.initial_observation_window;
+    for (int i = 0; i < EM_MAX_NODES; ++i) {
+        const double cap = i < c.n_nodes ? c.node_cpu_capacity[i] : 1.0;
+        k.cap[i] = cap;
+        k.inv_cap[i] = 1.0 / cap;
+    }
+    k.inv_k[0] = 0.0;
+    for (int i = 1; i <= EM_MAX_NODES; ++i) k.inv_k[i] = 1.0 / (double)i;
+    return k;
+}
+
 EnvParams make_params(const em_handle* h, int lanes)
 {
     const em_config& c = h->cfg;
@@ -649,26 +736,18 @@ EnvParams make_params(const em_handle* h, int lanes)
     std::memset(&p, 0, sizeof p);
     p.n = c.n_nodes;
     p.horizon = c.episode_length;
-    p.rate_mode = c.arrival_mode;
+    p.rate_mode = c.arrival_rate_lo == c.arrival_rate_hi ? 3 : c.arrival_mode;
     p.explore = h->explore_off ? 0 : 1;
     p.rec_bytes = rec_bytes(p.n);
     p.obs_floats = p.n * (p.n + 4);
     const int epw = 64 / lanes;
     int wb = epw * p.rec_bytes;
     wb += (epw * p.obs_floats * 4 + 15) & ~15;
-    wb += p.n * 8;                 // capacities
+    wb += (3 * p.n + 1) * 8;       // capacity, 1/capacity and 1/k tables
     wb += 2 * epw * p.n * 8;       // latencies, energies of the step
     wb += (epw * p.n * 4 + 7) & ~7;   // load ratios
     wb += epw * PRE_LANES * 20;    // pre-drawn environment-level random numbers
     p.wave_bytes = (wb + 15) & ~15;
-    p.rate_lo = c.arrival_rate_lo; p.rate_hi = c.arrival_rate_hi; p.cycle = c.arrival_cycle_seconds;
-    p.wl_lo = c.workload_lo; p.wl_hi = c.workload_hi;
-    p.data_lo = c.data_lo; p.data_hi = c.data_hi;
-    p.ddl_lo = c.deadline_lo; p.ddl_hi = c.deadline_hi;
-    p.bw_lo = c.bw_lo; p.bw_hi = c.bw_hi;
-    p.lat_lo = c.net_latency_lo; p.lat_hi = c.net_latency_hi;
-    p.w_lat = c.w_latency; p.w_en = c.w_energy; p.w_viol = c.w_violation;
-    p.dt_min = c.min_time_step; p.dt_max = c.max_time_step; p.window0 = c.initial_observation_window;
     // _get_current_epsilon, MRRL.PY:249-256
     double eps = 0.0;
     if (!h->explore_off) {
@@ -702,7 +781,7 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     if (tape) tp = *tape;
     const dim3 grid((unsigned)blocks), block(256);
 #define EM_LAUNCH(L)                                                                                              \
-    hipLaunchKernelGGL((env_kernel<L, TAPE, RESET>), grid, block, lds, s, p, h->d_state, h->d_cap, placement,     \
+    hipLaunchKernelGGL((env_kernel<L, TAPE, RESET>), grid, block, lds, s, p, h->d_state, h->d_const, placement,     \
                        resource, tp, *out, h->d_lat_log, h->d_err)
     if (lds > 64 * 1024) {
         hipError_t e = hipSuccess;
@@ -773,8 +852,11 @@ int em_create(const em_config* cfg, int64_t n_envs, int device_id, uint64_t seed
     const size_t sbytes = (size_t)n_envs * rec_bytes(cfg->n_nodes);
     hipError_t e = hipMalloc(&h->d_state, sbytes);
     if (e == hipSuccess) e = hipMemset(h->d_state, 0, sbytes);
-    if (e == hipSuccess) e = hipMalloc(&h->d_cap, sizeof(double) * EM_MAX_NODES);
-    if (e == hipSuccess) e = hipMemcpy(h->d_cap, cfg->node_cpu_capacity, sizeof(double) * EM_MAX_NODES, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&h->d_const, sizeof(EnvConst));
+    if (e == hipSuccess) {
+        const EnvConst k = make_const(*cfg);
+        e = hipMemcpy(h->d_const, &k, sizeof k, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&h->d_err, sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(h->d_err, 0, sizeof(int32_t));
     if (e == hipSuccess && h->lat_cap > 0) {
@@ -795,7 +877,7 @@ int em_destroy(em_handle* h)
     if (!h) return EM_OK;
     (void)hipSetDevice(h->device);
     if (h->d_state) (void)hipFree(h->d_state);
-    if (h->d_cap) (void)hipFree(h->d_cap);
+    if (h->d_const) (void)hipFree(h->d_const);
     if (h->d_lat_log) (void)hipFree(h->d_lat_log);
     if (h->d_sort_scratch) (void)hipFree(h->d_sort_scratch);
     if (h->d_err) (void)hipFree(h->d_err);
@@ -847,7 +929,7 @@ int em_episode_metrics(em_handle* h, double* out6, void* stream)
     if (lds > 64 * 1024)
         EM_HIP(hipFuncSetAttribute((const void*)metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, (hipStream_t)stream, p, h->d_state,
-                       h->d_cap, h->d_lat_log, h->d_sort_scratch, out6);
+                       h->d_const, h->d_lat_log, h->d_sort_scratch, out6);
     return em::hip_check(hipGetLastError(), "metrics_kernel launch");
 }
 

@@ -1,0 +1,67 @@
+// Cycle stamps of one wavefront of the env step kernel (phase by phase), for optimisation work.
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DEM_STAMP -Iinclude -Imarl_amd/csrc \
+//             tools/stamp_env.hip marl_amd/csrc/em_common.cpp -o tools/_stamp_env
+// Run:    tools/_stamp_env [n_envs] [explore]
+#include "../marl_amd/csrc/edge_env.hip"
+
+#include <cstdlib>
+
+int main(int argc, char** argv)
+{
+    const int64_t B = argc > 1 ? atoll(argv[1]) : 4096;
+    const int explore = argc > 2 ? atoi(argv[2]) : 0;
+    em_config c;
+    std::memset(&c, 0, sizeof c);
+    c.n_nodes = 10; c.episode_length = 1000; c.arrival_mode = 1; c.disable_env_exploration = !explore;
+    const double caps[10] = {1.0e9, 1.2e9, 1.4e9, 1.6e9, 1.8e9, 2.0e9, 2.2e9, 2.4e9, 2.6e9, 3.0e9};
+    for (int i = 0; i < 10; ++i) c.node_cpu_capacity[i] = caps[i];
+    c.arrival_rate_lo = 5; c.arrival_rate_hi = 15; c.arrival_cycle_seconds = 20;
+    c.workload_lo = 1; c.workload_hi = 10; c.data_lo = 0.5; c.data_hi = 5; c.deadline_lo = 0.05; c.deadline_hi = 0.5;
+    c.bw_lo = 10; c.bw_hi = 100; c.net_latency_lo = 0.002; c.net_latency_hi = 0.01;
+    c.w_latency = 0.5; c.w_energy = 0.3; c.w_violation = 0.2;
+    c.min_time_step = 0.02; c.max_time_step = 0.2; c.initial_observation_window = 0.1;
+    c.initial_epsilon = 1.0; c.final_epsilon = 0.05; c.decay_steps = 1000000;
+    em_handle* h = nullptr;
+    if (em_create(&c, B, 0, 7, 0, 0, &h)) { printf("create: %s\n", em_last_error()); return 1; }
+    const int n = 10;
+    std::vector<int32_t> pl(B * n);
+    std::vector<float> rs(B * n);
+    for (int64_t i = 0; i < B * n; ++i) { pl[i] = (int)((i * 7 + i / 10) % n); rs[i] = 0.1f + 0.9f * (float)((i * 37) % 100) / 100.f; }
+    int32_t* d_pl; float* d_rs; float* d_obs; uint64_t* d_act; double* d_rew; uint8_t* d_done;
+    hipMalloc(&d_pl, B * n * 4); hipMalloc(&d_rs, B * n * 4); hipMalloc(&d_obs, B * n * (n + 4) * 4);
+    hipMalloc(&d_act, B * 8); hipMalloc(&d_rew, B * 8); hipMalloc(&d_done, B);
+    hipMemcpy(d_pl, pl.data(), B * n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_rs, rs.data(), B * n * 4, hipMemcpyHostToDevice);
+    em_step_out out;
+    std::memset(&out, 0, sizeof out);
+    out.obs = d_obs; out.active = d_act; out.reward_seen = d_rew; out.done = d_done;
+    if (em_reset(h, nullptr, 0, 0, &out, nullptr)) { printf("reset: %s\n", em_last_error()); return 1; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 50; ++i) em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
+    hipDeviceSynchronize();
+    const int K = 500;
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < K; ++i) em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("B=%lld explore=%d: %.2f us/step\n", (long long)B, explore, ms * 1e3 / K);
+    unsigned long long st[16];
+    double acc[16] = {0};
+    const int R = 20;
+    for (int r = 0; r < R; ++r) {
+        em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(em_stamps), sizeof st);
+        for (int i = 1; i < 12; ++i) acc[i] += (double)(st[i] - st[i - 1]);
+    }
+    const char* names[12] = {"", "stage-in", "placement(par)", "chain", "reward", "pre-draw(philox A)", "rate", "dt/window",
+                             "poisson", "arrival loop", "decay/outputs", "stage-out"};
+    double tot = 0;
+    for (int i = 1; i < 12; ++i) { printf("  %-20s %8.0f cycles\n", names[i], acc[i] / R); tot += acc[i] / R; }
+    printf("  %-20s %8.0f cycles (s_memtime ticks)\n", "total", tot);
+    em_destroy(h);
+    return 0;
+}
