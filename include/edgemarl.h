@@ -127,6 +127,9 @@ int64_t em_record_bytes(const em_handle *h);
 int64_t em_n_envs(const em_handle *h);
 /* Kernel variant: lanes per environment (16/32/64); 0 restores the automatic choice. */
 int em_set_lanes_per_env(em_handle *h, int lanes);
+/* Kernel variant: wavefronts per workgroup of the reset/step kernel (waves - 1 worker wavefronts and one
+ * scalar wavefront, 2..8); 0 restores the default.  Results do not depend on it. */
+int em_set_workgroup_waves(em_handle *h, int waves);
 
 
 /* ------------------------------------------------------------------------------------------------

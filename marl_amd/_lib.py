@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     L.em_n_envs.argtypes = [vp]
     L.em_n_envs.restype = i64
     L.em_set_lanes_per_env.argtypes = [vp, i32]
+    L.em_set_workgroup_waves.argtypes = [vp, i32]
     L.em_mlp3_forward.argtypes = [C.POINTER(EmMlp3), vp, i64, i64, vp, vp]
     L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
@@ -98,7 +99,7 @@ def lib() -> C.CDLL:
                  "em_ppo_critic_grad", "em_adam_step"):
         getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
-                 "em_get_state", "em_set_lanes_per_env"):
+                 "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -32,7 +32,7 @@
 // -DEM_STAMP); compiled out of the library.
 #ifdef EM_STAMP
 __device__ unsigned long long em_stamps[16];
-#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) em_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || (threadIdx.x == blockDim.x - 64 && (i) >= 12))) em_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -57,6 +57,7 @@ struct EnvParams {
     int32_t n, horizon, rate_mode, explore;
     int32_t rec_bytes, obs_floats, wave_bytes, pad0;
     double eps;
+    int32_t step_no, pad1;       // 1-based index of the step being taken (all environments of a handle move together)
     uint32_t seed_lo, seed_hi, episode, env_offset;
     int64_t n_envs, lat_cap;
 };
@@ -187,12 +188,14 @@ __device__ inline double np_sum_small(const double* a, int n)
     return 0.0 + res;
 }
 
-// Lane-parallel pre-draw of the environment-level random numbers: lane 0 of an environment's group
-// evaluates the P_DT block, lanes 1..3 the first three P_POIS blocks (six uniforms of the Knuth
-// loop), lanes 4..9 P_TASK_A and lanes 10..15 P_TASK_B of the first six arrivals.  Later Poisson
-// uniforms / arrivals (rare) are evaluated inline by the group.  The stream is counter addressed,
-// so this is bit-identical to drawing them one after the other (oracle/edge_oracle.c does that).
-enum { PRE_LANES = 16, PRE_POIS_U = 6, PRE_TASKS = 6 };
+// Arrivals 0..PAR_TASKS-1 of a step are drawn in parallel, one Philox block per lane, before the state
+// record has even arrived (lanes 0..7: P_TASK_A, lanes 8..15: P_TASK_B); later arrivals (rare) are drawn
+// inline.  The stream is counter addressed, so this is bit-identical to drawing them one after the other
+// (oracle/edge_oracle.c does that).
+enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512 };
+#ifndef EM_ENV_MIN_WAVES
+#define EM_ENV_MIN_WAVES 6     // wavefronts per SIMD the register allocation aims for
+#endif
 
 template <int LPE>
 __device__ inline uint64_t group_bits(uint64_t ballot, int g)
@@ -204,29 +207,43 @@ __device__ inline uint64_t group_bits(uint64_t ballot, int g)
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
+// Workgroup layout: blockDim.x / 64 - 1 WORKER wavefronts (each owns 64/LPE environments, agents on lanes)
+// plus ONE SCALAR wavefront (the last) that evaluates, one environment per lane, the per-environment
+// scalar chain of _generate_tasks_and_obs: arrival rate -> time window -> Poisson arrival count
+// (MRRL.PY:220-247,350-351).  That chain does not depend on the placements, so it runs beside the
+// workers' placement phase and is handed over through LDS at the workgroup's single barrier; run on the
+// workers it would be evaluated redundantly on all LPE lanes of every group.
 template <int LPE, bool TAPE, bool RESET>
-__global__ __launch_bounds__(256, 6) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
+__global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
                                                   const EnvConst* __restrict__ cc,
                                                   const int32_t* __restrict__ placement,
                                                   const float* __restrict__ resource, const em_tape tape,
                                                   const em_step_out out, double* __restrict__ lat_log,
                                                   int32_t* __restrict__ err_flag)
 {
-    constexpr int EPW = 64 / LPE;   // environments per wavefront
+    constexpr int EPW = 64 / LPE;   // environments per worker wavefront
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int n = p.n, w = n + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane / LPE, sl = lane % LPE;
-    const int64_t env0 = ((int64_t)blockIdx.x * 4 + wave) * EPW;   // first environment of this wavefront
-    if (env0 >= p.n_envs) return;                                     // whole wavefront idle (no barriers below)
-    const int n_valid = (int)((p.n_envs - env0) < EPW ? (p.n_envs - env0) : EPW);
+    const int n_work = (int)(blockDim.x >> 6) - 1;
+    const bool scalar_wave = wave == n_work;
+    const int64_t env_b0 = (int64_t)blockIdx.x * (n_work * EPW);   // first environment of the workgroup
+    const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
+    double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [64] window per environment
+    int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
+
+    // worker coordinates (meaningless on the scalar wavefront)
+    const int g = lane / LPE, sl = lane % LPE, gbase = g * LPE;
+    const int64_t env0 = env_b0 + (int64_t)wave * EPW;
+    const int n_valid = (scalar_wave || env0 >= p.n_envs) ? 0 : (int)((p.n_envs - env0) < EPW ? (p.n_envs - env0) : EPW);
     const int64_t env = env0 + g;
     const bool valid = g < n_valid;
     const bool agent = valid && sl < n;
+    const uint32_t envid = p.env_offset + (uint32_t)env;
 
-    // LDS carve-up for this wavefront
-    unsigned char* wbase = smem + wave * p.wave_bytes;
+    // LDS carve-up of a worker wavefront
+    unsigned char* wbase = smem + (scalar_wave ? 0 : wave) * p.wave_bytes;
     unsigned char* rec = wbase + g * p.rec_bytes;
     double* r_load = reinterpret_cast<double*>(rec);
     double* r_wl = r_load + n;
@@ -236,318 +253,405 @@ __global__ __launch_bounds__(256, 6) void env_kernel(const EnvParams p, unsigned
     int32_t* r_queue = reinterpret_cast<int32_t*>(rec + rec_off_queue(n));
     int32_t* r_int = reinterpret_cast<int32_t*>(rec + rec_off_int(n));
     int8_t* r_rank = reinterpret_cast<int8_t*>(rec + rec_off_rank(n));
+    const int slots = n < 8 ? 8 : n;                   // latency/energy slots per environment (>= 8: batched reads)
     int off = EPW * p.rec_bytes;
     float* s_obs_w = reinterpret_cast<float*>(wbase + off);
     float* s_obs = s_obs_w + g * p.obs_floats;
     off += (EPW * p.obs_floats * 4 + 15) & ~15;
-    double* s_cap = reinterpret_cast<double*>(wbase + off);      // capacity, 1/capacity, 1/k tables
-    double* s_icap = s_cap + n;
-    double* s_ik = s_icap + n;
-    off += (3 * n + 1) * 8;
-    double* s_lat = reinterpret_cast<double*>(wbase + off) + g * n;
-    off += EPW * n * 8;
-    double* s_en = reinterpret_cast<double*>(wbase + off) + g * n;
-    off += EPW * n * 8;
+    double* s_lat = reinterpret_cast<double*>(wbase + off) + g * slots;
+    off += EPW * slots * 8;
+    double* s_en = reinterpret_cast<double*>(wbase + off) + g * slots;
+    off += EPW * slots * 8;
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(wbase + off) + g;   // ranks of the acting agents
+    off += EPW * 8;
     float* s_ratio = reinterpret_cast<float*>(wbase + off) + g * n;
-    off += (EPW * n * 4 + 7) & ~7;
-    // environment-level draws of the step, produced by one Philox block per lane (philox mode only)
-    double* s_ra = reinterpret_cast<double*>(wbase + off) + g * PRE_LANES;
-    off += EPW * PRE_LANES * 8;
-    double* s_rb = reinterpret_cast<double*>(wbase + off) + g * PRE_LANES;
-    off += EPW * PRE_LANES * 8;
-    int32_t* s_rz = reinterpret_cast<int32_t*>(wbase + off) + g * PRE_LANES;
+    off += EPW * n * 4;
+    int32_t* s_first = reinterpret_cast<int32_t*>(wbase + off) + g * n;   // first arrival index per decider
 
-    // the step's actions do not depend on the staged record: issue their loads first
-    int tgt_in = -1;
-    float res_in = 1.0f;
-    if constexpr (!RESET) {
-        if (agent) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
-    }
+    // values that live across the barrier
+    double reward = 0.0, t_now = 0.0, cap_me = 1.0, icap_me = 1.0;
+    int draws_lane = 0;
+    // pre-drawn task of lane sl < PAR_TASKS (philox mode)
+    double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
+    int pre_dec = 0;
 
-    STAMP(0);
-    // ---- stage in: records (or zeros at reset), zeroed observation tile, capacity table ---------
-    {
-        uint4* dst = reinterpret_cast<uint4*>(wbase);
+    if (scalar_wave) {
+        // =========================== scalar wavefront: one environment per lane ===========================
+        STAMP(12);
+        const int64_t e = env_b0 + lane;
+        const bool v = lane < n_work * EPW && e < p.n_envs;
+        const uint32_t eid = p.env_offset + (uint32_t)e;
+        double t0 = 0.0;
+        if constexpr (!RESET) {
+            if (v) t0 = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
+        }
+        double rate_u = 0.0, dt_u = 0.0;
+        double pu[PRE_POIS_U] = {0.0};     // first uniforms of the Knuth loop, drawn while the clock loads
+        if constexpr (!TAPE) {
+            const uint4 b = philox(eid, p.episode, step_no, (P_DT << 24), p.seed_lo, p.seed_hi);
+            dt_u = u53(b.x, b.y);
+            rate_u = cc->rate_lo + cc->rate_span * u53(b.z, b.w);
+#pragma unroll
+            for (int i = 0; i < PRE_POIS_U / 2; ++i) {
+                const uint4 q = philox(eid, p.episode, step_no, (P_POIS << 24) | (uint32_t)i, p.seed_lo, p.seed_hi);
+                pu[2 * i] = u53(q.x, q.y);
+                pu[2 * i + 1] = u53(q.z, q.w);
+            }
+        }
+        double rate;
+        if (p.rate_mode == 3) rate = cc->rate_lo;      // degenerate range (MRRL.PY:222-223)
+        else if (p.rate_mode == 1) {
+            const double cyc = cc->cycle, icyc = cc->inv_cycle;   // cycle already clamped to >= 1e-6 (MRRL.PY:226)
+            const double phase = qdiv(exact_fmod_pos(t0, cyc, icyc), cyc, icyc);
+            // tape mode never uses the rate (dt and the arrival count come pre-drawn)
+            rate = cc->rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * cc->rate_span;
+        } else if (p.rate_mode == 2) {
+            if constexpr (TAPE) rate_u = v ? tape.rate_u[e] : 0.0;
+            rate = rate_u;
+        } else rate = cc->rate_mid;
+        const double rate_c = rate > 1e-6 ? rate : 1e-6;
+
+        double window;
+        if constexpr (RESET) window = cc->window0;
+        else {
+            double raw;
+            if constexpr (TAPE) raw = v ? tape.dt_raw[e] : 0.0;
+            else raw = (1.0 / rate_c) * (-det_log(1.0 - dt_u));
+            const double dt_min = cc->dt_min, dt_max = cc->dt_max;
+            window = raw < dt_min ? dt_min : (raw > dt_max ? dt_max : raw);   // MRRL.PY:247
+        }
+        STAMP(13);
+        int n_new = 0;
+        if constexpr (TAPE) {
+            n_new = v ? tape.n_arrivals[e] : 0;
+            if (n_new > tape.arrival_slots || n_new < 0) { atomicOr(err_flag, 2); n_new = 0; }
+        } else if (v) {
+            const double limit = det_exp(-(rate_c * window));
+            double prod = 1.0;
+            bool going = true;
+#pragma unroll
+            for (int i = 0; i < PRE_POIS_U; ++i) {   // Knuth multiplication method on the pre-drawn uniforms
+                prod = prod * pu[i];
+                going = going && prod > limit;
+                n_new += going ? 1 : 0;
+            }
+            if (going) {
+                uint4 b = make_uint4(0, 0, 0, 0);
+                for (uint32_t i = PRE_POIS_U;; ++i) {   // rare tail; ends at n_new == 4096 at the latest
+                    if ((i & 1u) == 0u) b = philox(eid, p.episode, step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
+                    const double u = (i & 1u) ? u53(b.z, b.w) : u53(b.x, b.y);
+                    prod = prod * u;
+                    if (prod > limit && n_new < 4096) ++n_new; else break;
+                }
+            }
+        }
+        s_win[lane] = window;
+        s_nnew[lane] = n_new;
+        STAMP(14);
+    } else {
+        // =========================== worker wavefront, part 1: placements ================================
+        STAMP(0);
+        // global loads first: actions, capacity tables, the records
+        int tgt_in = -1;
+        float res_in = 1.0f;
+        double ik_lane = 0.0;
+        if (agent) {
+            cap_me = cc->cap[sl];
+            icap_me = cc->inv_cap[sl];
+            ik_lane = cc->inv_k[sl + 1];
+            if constexpr (!RESET) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+        }
+        uint4* ldst = reinterpret_cast<uint4*>(wbase);
         const int nvec = n_valid * p.rec_bytes / 16;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+        if constexpr (!RESET) {
+            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+            if (lane < nvec) v0 = src[lane];
+            if (lane + 64 < nvec) v1 = src[lane + 64];
+        }
+
+        // random numbers that depend only on (environment, step, lane): evaluated while the loads fly
+        double net_bw = 0.0, net_lat = 0.0, ex_u = 2.0, ex_res = 0.0;
+        int ex_tgt = 0;
+        if constexpr (!TAPE) {
+            if (sl < 2 * PAR_TASKS) {
+                // lanes 0..7: P_TASK_A of arrival sl (workload, data); lanes 8..15: P_TASK_B of arrival sl-8
+                const bool is_a = sl < PAR_TASKS;
+                const uint4 b = philox(envid, p.episode, step_no,
+                                       ((is_a ? P_TASK_A : P_TASK_B) << 24) | (uint32_t)(is_a ? sl : sl - PAR_TASKS),
+                                       p.seed_lo, p.seed_hi);
+                const double ra = (is_a ? cc->wl_lo : cc->ddl_lo) + (is_a ? cc->wl_span : cc->ddl_span) * u53(b.x, b.y);
+                const double rb = cc->data_lo + cc->data_span * u53(b.z, b.w);
+                const int rz = (int)__umulhi(b.z, (uint32_t)n);
+                pre_wl = ra;
+                pre_data = rb;
+                pre_offs = __shfl_xor(ra, PAR_TASKS);     // lane j < 8 takes the deadline offset and the decider
+                pre_dec = __shfl_xor(rz, PAR_TASKS);      // of arrival j from lane j + 8
+            }
+            if constexpr (!RESET) {
+                if (agent) {
+                    const uint4 b = philox(envid, p.episode, step_no, (P_NET << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                    net_bw = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
+                    net_lat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
+                    if (p.explore) {
+                        const uint4 e1 = philox(envid, p.episode, step_no, (P_EXPL << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                        ex_u = u53(e1.x, e1.y);
+                        ex_tgt = (int)__umulhi(e1.z, (uint32_t)n);
+                        if (!(ex_u > p.eps)) {
+                            const uint4 e2 = philox(envid, p.episode, step_no, (P_EXPL_RES << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                            ex_res = 0.1 + (1.0 - 0.1) * u53(e2.x, e2.y);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- stage in: records (zeros at reset), zeroed observation tile, per-step scratch -----------
+        const int nstage = RESET ? EPW * p.rec_bytes / 16 : nvec;
+        if (lane < nstage) ldst[lane] = v0;
+        if (lane + 64 < nstage) ldst[lane + 64] = v1;
         if constexpr (RESET) {
-            for (int i = lane; i < EPW * p.rec_bytes / 16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
-            for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
         }
-        uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
-        for (int i = lane; i < ((EPW * p.obs_floats * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < n; i += 64) { s_cap[i] = cc->cap[i]; s_icap[i] = cc->inv_cap[i]; }
-        for (int i = lane; i <= n; i += 64) s_ik[i] = cc->inv_k[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const double cap_me = agent ? s_cap[sl] : 1.0;
-    const double icap_me = agent ? s_icap[sl] : 1.0;
-    const uint32_t envid = p.env_offset + (uint32_t)env;
-    const int step_no = RESET ? 0 : r_int[I_STEP] + 1;
-    const double t_now = RESET ? 0.0 : r_scal[S_TIME];
-    int draws_lane = 0;       // draws made on behalf of this lane's agent
-    int draws_env = 0;        // draws made once per environment (uniform in the group)
-    double reward = 0.0;
-
-    if constexpr (!RESET) {
-        STAMP(1);
-        // ---- placement phase: per-agent quantities in parallel on the lanes (MRRL.PY:397-423) ----
-        int rank = agent ? (int)r_rank[sl] : -1;
-        int tgt = tgt_in;
-        bool acting = rank >= 0 && tgt >= 0 && tgt < n;
-        float res = acting ? res_in : 1.0f;
-        const double wl = acting ? r_wl[sl] : 1.0;
-        const double data = acting ? r_data[sl] : 1.0;
-        const double ddl = acting ? r_ddl[sl] : 0.0;
-
-        int slot = rank;   // acting slot = number of acting agents that arrived earlier
-        if constexpr (TAPE) {
-            const int key = acting ? rank : 127;
-            slot = 0;
-            for (int j = 0; j < n; ++j) {
-                const int other = __shfl(key, g * LPE + j);
-                slot += (other < key) ? 1 : 0;
-            }
-        }
-
-        if (p.explore && acting) {   // _maybe_apply_env_exploration, MRRL.PY:258-274
-            double u;
-            uint32_t tgt_bits = 0;
-            if constexpr (TAPE) u = tape.explore_u[env * n + slot];
-            else {
-                const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_EXPL << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
-                u = u53(b.x, b.y);
-                tgt_bits = b.z;
-            }
-            draws_lane += 1;
-            if (!(u > p.eps)) {
-                double r64;
-                if constexpr (TAPE) {
-                    tgt = tape.explore_tgt[env * n + slot];
-                    r64 = tape.explore_res[env * n + slot];
-                    if (tgt < 0 || tgt >= n) { atomicOr(err_flag, 1); tgt = 0; }
-                } else {
-                    tgt = (int)__umulhi(tgt_bits, (uint32_t)n);
-                    const uint4 b2 = philox(envid, p.episode, (uint32_t)step_no, (P_EXPL_RES << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
-                    r64 = 0.1 + (1.0 - 0.1) * u53(b2.x, b2.y);
-                }
-                res = (float)r64;
-                draws_lane += 2;
-            }
-        }
-
-        double t_trans = 0.0;
-        if (acting && tgt != sl) {   // MRRL.PY:409-414
-            double bw_u, nlat;
-            if constexpr (TAPE) { bw_u = tape.bw_u[env * n + slot]; nlat = tape.net_lat[env * n + slot]; }
-            else {
-                const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_NET << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
-                bw_u = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
-                nlat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
-            }
-            draws_lane += 2;
-            const double bw = bw_u * 1e6 / 8;
-            t_trans = (data / bw) + nlat;
-        }
-        const double cap_t = acting ? s_cap[tgt] : 1.0;
-        const double icap_t = acting ? s_icap[tgt] : 1.0;
-        const double alloc = cap_t * (double)res;        // MRRL.PY:418 (float64 * float32)
-        const double gcyc = qdiv(alloc, 1e9, 1e-9);
-        const double t_exec = wl / gcyc;                  // MRRL.PY:419
-        const double energy = wl * gcyc;                  // MRRL.PY:423
-        const double inc = t_exec * gcyc;                 // MRRL.PY:437
-
-        STAMP(2);
-        // ---- ordered chain over arrival rank: queueing delay sees earlier placements (MRRL.PY:416,437)
-        int k = 0;
-        bool viol = false;
-        for (int r = 0; r < n; ++r) {
-            if (__ballot(acting && rank >= r) == 0ull) break;
-            const bool mine = acting && rank == r;
-            const uint64_t bal = __ballot(mine);
-            if (mine) {
-                const double l = r_load[tgt];
-                const double t_queue = qdiv(l, cap_t, icap_t);
-                const double t_total = t_trans + t_queue + t_exec;
-                viol = (t_now + t_total) > ddl;          // MRRL.PY:431
-                s_lat[k] = t_total;
-                s_en[k] = energy;
-                r_load[tgt] = l + inc;
-                r_queue[tgt] += 1;
-            }
-            k += group_bits<LPE>(bal, g) != 0ull ? 1 : 0;
-            __builtin_amdgcn_wave_barrier();
-        }
-        const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g));
-        __builtin_amdgcn_wave_barrier();
-
-        STAMP(3);
-        // ---- reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466) ----------------
-        if (k > 0) {
-            const double kd = (double)k, ik = s_ik[k];
-            const double cost = (cc->w_lat * qdiv(np_sum_small(s_lat, k), kd, ik)) +
-                                (cc->w_en * qdiv(np_sum_small(s_en, k), kd, ik)) + (cc->w_viol * (double)n_viol);
-            reward = -cost;
-        }
-        const int tasks_before = r_int[I_TASKS];
-        if (valid && sl == 0) {
-            double sl_acc = r_scal[S_SUMLAT], se_acc = r_scal[S_SUMEN];
-            for (int i = 0; i < k; ++i) { sl_acc += s_lat[i]; se_acc += s_en[i]; }
-            r_scal[S_SUMLAT] = sl_acc;
-            r_scal[S_SUMEN] = se_acc;
-            r_int[I_TASKS] = tasks_before + k;
-            r_int[I_VIOL] += n_viol;
-            r_int[I_DONE] += k - n_viol;
-        }
-        if (agent) {
-            if (out.step_latency) out.step_latency[env * n + sl] = sl < k ? s_lat[sl] : __builtin_nan("");
-            if (lat_log && sl < k) {
-                const int64_t at = (int64_t)tasks_before + sl;
-                if (at < p.lat_cap) lat_log[env * p.lat_cap + at] = s_lat[sl];
-            }
-        }
-        if (lat_log && valid && sl == 0) {
-            const int64_t end = (int64_t)tasks_before + k;
-            r_int[I_LOGGED] = (int32_t)(end < p.lat_cap ? end : p.lat_cap);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    STAMP(4);
-    // ---- arrivals (MRRL.PY:340-383) ----------------------------------------------------------------
-    if (agent) {
-        r_rank[sl] = -1;
-        s_ratio[sl] = (float)qdiv(r_load[sl], cap_me, icap_me);   // load/cap BEFORE this step's decay
-    }
-    double rate_u = 0.0, dt_u = 0.0;
-    if constexpr (!TAPE) {
-        if (sl < PRE_LANES) {
-            const bool is_dt = sl == 0, is_pois = sl >= 1 && sl < 4, is_a = sl >= 4 && sl < 10;
-            const uint32_t purpose = is_dt ? P_DT : (is_pois ? P_POIS : (is_a ? P_TASK_A : P_TASK_B));
-            const uint32_t index = is_dt ? 0u : (uint32_t)(is_pois ? sl - 1 : (is_a ? sl - 4 : sl - 10));
-            const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (purpose << 24) | index, p.seed_lo, p.seed_hi);
-            // value = lo + span * u; (lo, span) = (0, 1) leaves a raw uniform unchanged, bit for bit
-            const double lo_a = is_dt || is_pois ? 0.0 : (is_a ? cc->wl_lo : cc->ddl_lo);
-            const double sp_a = is_dt || is_pois ? 1.0 : (is_a ? cc->wl_span : cc->ddl_span);
-            const double lo_b = is_dt ? cc->rate_lo : (is_a ? cc->data_lo : 0.0);
-            const double sp_b = is_dt ? cc->rate_span : (is_a ? cc->data_span : 1.0);
-            s_ra[sl] = lo_a + sp_a * u53(b.x, b.y);
-            s_rb[sl] = lo_b + sp_b * u53(b.z, b.w);
-            s_rz[sl] = (int32_t)__umulhi(b.z, (uint32_t)n);
+        {
+            uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
+            for (int i = lane; i < ((EPW * p.obs_floats * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
+            if (sl == 0) *s_mask = 0ull;
+            if (sl < n) s_first[sl] = 0x7fffffff;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        dt_u = s_ra[0];
-        rate_u = s_rb[0];
-    }
-    STAMP(5);
-    double rate;
-    if (p.rate_mode == 3) rate = cc->rate_lo;      // degenerate range (MRRL.PY:222-223)
-    else if (p.rate_mode == 1) {
-        const double cyc = cc->cycle, icyc = cc->inv_cycle;   // cycle already clamped to >= 1e-6 (MRRL.PY:226)
-        const double phase = qdiv(exact_fmod_pos(t_now, cyc, icyc), cyc, icyc);
-        // tape mode never uses the rate (dt and the arrival count come pre-drawn)
-        rate = cc->rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * cc->rate_span;
-    } else if (p.rate_mode == 2) {
-        if constexpr (TAPE) rate_u = valid ? tape.rate_u[env] : 0.0;
-        rate = rate_u;
-        draws_env += 1;
-    } else rate = cc->rate_mid;
-    const double rate_c = rate > 1e-6 ? rate : 1e-6;
+        STAMP(1);
 
-    STAMP(6);
-    double window;
-    if constexpr (RESET) window = cc->window0;
-    else {
-        double raw;
-        if constexpr (TAPE) raw = valid ? tape.dt_raw[env] : 0.0;
-        else raw = (1.0 / rate_c) * (-det_log(1.0 - dt_u));
-        draws_env += 1;
-        const double dt_min = cc->dt_min, dt_max = cc->dt_max;
-        window = raw < dt_min ? dt_min : (raw > dt_max ? dt_max : raw);   // MRRL.PY:247
-    }
+        if constexpr (!RESET) {
+            t_now = r_scal[S_TIME];
+            // ---- placement phase: per-agent quantities in parallel on the lanes (MRRL.PY:397-423) ----
+            const int rank = agent ? (int)r_rank[sl] : -1;
+            int tgt = tgt_in;
+            const bool acting = rank >= 0 && tgt >= 0 && tgt < n;
+            float res = acting ? res_in : 1.0f;
+            const double wl = acting ? r_wl[sl] : 1.0;
+            const double data = acting ? r_data[sl] : 1.0;
+            const double ddl = acting ? r_ddl[sl] : 0.0;
+            if (acting) atomicOr(s_mask, 1ull << rank);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long rmask = *s_mask;
+            // acting slot = number of acting agents that arrived earlier; k = acting agents of the environment
+            const int slot = acting ? __popcll(rmask & ((1ull << rank) - 1ull)) : -1;
+            const int k = valid ? __popcll(rmask) : 0;
 
-    STAMP(7);
-    int n_new = 0;
-    if constexpr (TAPE) {
-        n_new = valid ? tape.n_arrivals[env] : 0;
-        if (n_new > tape.arrival_slots || n_new < 0) { atomicOr(err_flag, 2); n_new = 0; }
-    } else if (valid) {
-        const double limit = det_exp(-(rate_c * window));
-        double prod = 1.0;
-        bool going = true;
-#pragma unroll
-        for (int i = 0; i < PRE_POIS_U; ++i) {   // Knuth multiplication method on the pre-drawn uniforms
-            const double u = (i & 1) ? s_rb[1 + (i >> 1)] : s_ra[1 + (i >> 1)];
-            prod = prod * u;
-            going = going && prod > limit;
-            n_new += going ? 1 : 0;
+            if (p.explore && acting) {   // _maybe_apply_env_exploration, MRRL.PY:258-274
+                if constexpr (TAPE) ex_u = tape.explore_u[env * n + slot];
+                draws_lane += 1;
+                if (!(ex_u > p.eps)) {
+                    if constexpr (TAPE) {
+                        ex_tgt = tape.explore_tgt[env * n + slot];
+                        ex_res = tape.explore_res[env * n + slot];
+                        if (ex_tgt < 0 || ex_tgt >= n) { atomicOr(err_flag, 1); ex_tgt = 0; }
+                    }
+                    tgt = ex_tgt;
+                    res = (float)ex_res;
+                    draws_lane += 2;
+                }
+            }
+
+            double t_trans = 0.0;
+            if (acting && tgt != sl) {   // MRRL.PY:409-414
+                if constexpr (TAPE) { net_bw = tape.bw_u[env * n + slot]; net_lat = tape.net_lat[env * n + slot]; }
+                draws_lane += 2;
+                const double bw = net_bw * 1e6 / 8;
+                t_trans = (data / bw) + net_lat;
+            }
+            // capacity of the target server: held by lane `tgt` of this group
+            const int tl = gbase + (acting ? tgt : sl);
+            const double cap_t = __shfl(cap_me, tl), icap_t = __shfl(icap_me, tl);
+            const double alloc = cap_t * (double)res;        // MRRL.PY:418 (float64 * float32)
+            const double gcyc = qdiv(alloc, 1e9, 1e-9);
+            const double t_exec = wl / gcyc;                  // MRRL.PY:419
+            const double energy = wl * gcyc;                  // MRRL.PY:423
+            const double inc = t_exec * gcyc;                 // MRRL.PY:437
+
+            STAMP(2);
+            // ---- ordered chain over acting slots: queueing delay sees earlier placements (MRRL.PY:416,437)
+            bool viol = false;
+            for (int s = 0; __ballot(acting && slot >= s) != 0ull; ++s) {
+                if (acting && slot == s) {
+                    const double l = r_load[tgt];
+                    const double t_queue = qdiv(l, cap_t, icap_t);
+                    const double t_total = t_trans + t_queue + t_exec;
+                    viol = (t_now + t_total) > ddl;          // MRRL.PY:431
+                    s_lat[s] = t_total;
+                    s_en[s] = energy;
+                    r_load[tgt] = l + inc;
+                    r_queue[tgt] += 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g));
+
+            STAMP(3);
+            // ---- reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466) ----------------
+            const int tasks_before = r_int[I_TASKS];
+            double sum_lat, sum_en, acc_lat = r_scal[S_SUMLAT], acc_en = r_scal[S_SUMEN];
+            if (__ballot(k > 4) == 0ull) {
+                // common case: one batch of LDS reads, sums in numpy's order for fewer than 8 addends
+                const double a0 = s_lat[0], a1 = s_lat[1], a2 = s_lat[2], a3 = s_lat[3];
+                const double e0 = s_en[0], e1 = s_en[1], e2 = s_en[2], e3 = s_en[3];
+                double rl = -0.0, re = -0.0;
+                if (k > 0) { rl += a0; re += e0; acc_lat += a0; acc_en += e0; }
+                if (k > 1) { rl += a1; re += e1; acc_lat += a1; acc_en += e1; }
+                if (k > 2) { rl += a2; re += e2; acc_lat += a2; acc_en += e2; }
+                if (k > 3) { rl += a3; re += e3; acc_lat += a3; acc_en += e3; }
+                sum_lat = 0.0 + rl;
+                sum_en = 0.0 + re;
+            } else {
+                sum_lat = np_sum_small(s_lat, k);
+                sum_en = np_sum_small(s_en, k);
+                for (int i = 0; i < k; ++i) { acc_lat += s_lat[i]; acc_en += s_en[i]; }
+            }
+            if (k > 0) {
+                const double kd = (double)k, ik = __shfl(ik_lane, gbase + k - 1);
+                const double cost = (cc->w_lat * qdiv(sum_lat, kd, ik)) + (cc->w_en * qdiv(sum_en, kd, ik)) +
+                                    (cc->w_viol * (double)n_viol);
+                reward = -cost;
+            }
+            if (agent) {
+                if (out.step_latency) out.step_latency[env * n + sl] = sl < k ? s_lat[sl] : __builtin_nan("");
+                if (lat_log && sl < k) {
+                    const int64_t at = (int64_t)tasks_before + sl;
+                    if (at < p.lat_cap) lat_log[env * p.lat_cap + at] = s_lat[sl];
+                }
+            }
+            if (valid && sl == 0) {
+                r_scal[S_SUMLAT] = acc_lat;
+                r_scal[S_SUMEN] = acc_en;
+                r_int[I_TASKS] = tasks_before + k;
+                r_int[I_VIOL] += n_viol;
+                r_int[I_DONE] += k - n_viol;
+                if (lat_log) {
+                    const int64_t end = (int64_t)tasks_before + k;
+                    r_int[I_LOGGED] = (int32_t)(end < p.lat_cap ? end : p.lat_cap);
+                }
+            }
         }
-        if (going) {
-            uint4 b = make_uint4(0, 0, 0, 0);
-            for (uint32_t i = PRE_POIS_U;; ++i) {   // rare tail; ends at n_new == 4096 at the latest
-                if ((i & 1u) == 0u) b = philox(envid, p.episode, (uint32_t)step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
-                const double u = (i & 1u) ? u53(b.z, b.w) : u53(b.x, b.y);
-                prod = prod * u;
-                if (prod > limit && n_new < 4096) ++n_new; else break;
+        STAMP(4);
+    }
+
+    __syncthreads();   // the scalar wavefront's windows and arrival counts are in LDS
+    if (scalar_wave) return;
+
+    // =============================== worker wavefront, part 2: arrivals (MRRL.PY:340-383) ===============
+    STAMP(5);
+    const double window = s_win[wave * EPW + g];
+    const int n_new = valid ? s_nnew[wave * EPW + g] : 0;
+    float ratio_me = 0.0f;
+    if (agent) {
+        r_rank[sl] = -1;
+        ratio_me = (float)qdiv(r_load[sl], cap_me, icap_me);   // load/cap BEFORE this step's decay
+        s_ratio[sl] = ratio_me;
+    }
+    // arrivals 0..PAR-1 in parallel, arrival j on lane j of the group
+    constexpr int PAR = TAPE ? 16 : PAR_TASKS;
+    const bool has = valid && sl < PAR && sl < n_new;
+    double a_wl = pre_wl, a_data = pre_data, a_offs = pre_offs;
+    int a_dec = pre_dec;
+    if constexpr (TAPE) {
+        if (has) {
+            const int64_t o = env * tape.arrival_slots + sl;
+            a_wl = tape.task_workload[o]; a_data = tape.task_data[o];
+            a_offs = tape.task_deadline_offset[o]; a_dec = tape.task_decider[o];
+            if (a_dec < 0 || a_dec >= n) { atomicOr(err_flag, 4); a_dec = 0; }
+        }
+    }
+    const double a_deadline = t_now + a_offs;              // MRRL.PY:217
+    if (has) atomicMin(&s_first[a_dec], sl);               // first arrival of each decider (MRRL.PY:358-362)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool is_new = has && s_first[a_dec] == sl;
+    const uint32_t new_bits = (uint32_t)group_bits<LPE>(__ballot(is_new), g);
+    const int first_me = agent ? s_first[sl] : 0x7fffffff;
+    const int q_me = agent ? r_queue[sl] : 0;              // queue length BEFORE this call's bumps (MRRL.PY:311)
+    const bool pend_me = first_me != 0x7fffffff;
+    if (is_new) {                                          // MRRL.PY:361 and the task columns of _get_obs
+        r_rank[a_dec] = (int8_t)__popc(new_bits & ((1u << sl) - 1u));
+        r_wl[a_dec] = a_wl; r_data[a_dec] = a_data; r_ddl[a_dec] = a_deadline;
+        const double rem = a_deadline - t_now;
+        float* row = s_obs + a_dec * w;
+        row[2] = (float)a_data;
+        row[3] = (float)a_wl;
+        row[4] = (float)(rem > 0 ? rem : 0.0);
+    }
+    if (pend_me) { s_obs[sl * w] = ratio_me; s_obs[sl * w + 1] = (float)q_me; }
+    // the other servers' load ratios: every lane writes its own ratio into the rows of the pending agents
+    {
+        uint64_t pm = group_bits<LPE>(__ballot(pend_me), g);
+        while (__ballot(pm != 0ull) != 0ull) {
+            if (pm != 0ull) {
+                const int r = __ffsll((unsigned long long)pm) - 1;
+                pm &= pm - 1ull;
+                if (agent && sl != r) s_obs[r * w + (sl < r ? sl + 5 : sl + 4)] = ratio_me;
             }
         }
     }
-    draws_env += 1;
+    if (has && !is_new) atomicAdd(&r_queue[a_dec], 1);    // MRRL.PY:359
+    int n_pending = __popc(new_bits);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    STAMP(8);
-    int n_pending = 0;
-    for (int j = 0;; ++j) {
-        const bool more = j < n_new;
-        if (__ballot(more) == 0ull) break;
-        if (more) {
-            double wl, data, offs;
-            int dec;
-            if constexpr (TAPE) {
-                const int64_t o = env * tape.arrival_slots + j;
-                wl = tape.task_workload[o]; data = tape.task_data[o];
-                offs = tape.task_deadline_offset[o]; dec = tape.task_decider[o];
-                if (dec < 0 || dec >= n) { atomicOr(err_flag, 4); dec = 0; }
-            } else if (j < PRE_TASKS) {
-                wl = s_ra[4 + j]; data = s_rb[4 + j]; offs = s_ra[10 + j]; dec = s_rz[10 + j];
-            } else {
-                const uint4 a = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_A << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
-                const uint4 b = philox(envid, p.episode, (uint32_t)step_no, (P_TASK_B << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
-                wl = cc->wl_lo + cc->wl_span * u53(a.x, a.y);
-                data = cc->data_lo + cc->data_span * u53(a.z, a.w);
-                offs = cc->ddl_lo + cc->ddl_span * u53(b.x, b.y);
-                dec = (int)__umulhi(b.z, (uint32_t)n);
-            }
-            draws_env += 4;
-            const double deadline = t_now + offs;          // MRRL.PY:217
-            const bool is_new = r_rank[dec] < 0;           // broadcast read, before any lane updates
-            const float q_now = (float)r_queue[dec];
-            if (sl == 0) {
-                if (is_new) {                               // MRRL.PY:361
-                    r_rank[dec] = (int8_t)n_pending;
-                    r_wl[dec] = wl; r_data[dec] = data; r_ddl[dec] = deadline;
-                } else r_queue[dec] += 1;                  // MRRL.PY:359
-            }
-            if (is_new) {                                   // _get_obs, MRRL.PY:307-324
-                const double rem = deadline - t_now;
-                for (int c = sl; c < w; c += LPE) {
-                    float v;
-                    if (c == 0) v = s_ratio[dec];
-                    else if (c == 1) v = q_now;
-                    else if (c == 2) v = (float)data;
-                    else if (c == 3) v = (float)wl;
-                    else if (c == 4) v = (float)(rem > 0 ? rem : 0.0);
-                    else { const int i = c - 5; v = s_ratio[i < dec ? i : i + 1]; }
-                    s_obs[dec * w + c] = v;
+    STAMP(6);
+    if (__ballot(n_new > PAR) != 0ull) {
+        // rare tail: arrivals beyond the parallel batch, one at a time in arrival order
+        for (int j = PAR;; ++j) {
+            const bool more = j < n_new;
+            if (__ballot(more) == 0ull) break;
+            if (more) {
+                double wl, data, offs;
+                int dec;
+                if constexpr (TAPE) {
+                    const int64_t o = env * tape.arrival_slots + j;
+                    wl = tape.task_workload[o]; data = tape.task_data[o];
+                    offs = tape.task_deadline_offset[o]; dec = tape.task_decider[o];
+                    if (dec < 0 || dec >= n) { atomicOr(err_flag, 4); dec = 0; }
+                } else {
+                    const uint4 a = philox(envid, p.episode, step_no, (P_TASK_A << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
+                    const uint4 b = philox(envid, p.episode, step_no, (P_TASK_B << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
+                    wl = cc->wl_lo + cc->wl_span * u53(a.x, a.y);
+                    data = cc->data_lo + cc->data_span * u53(a.z, a.w);
+                    offs = cc->ddl_lo + cc->ddl_span * u53(b.x, b.y);
+                    dec = (int)__umulhi(b.z, (uint32_t)n);
                 }
-                n_pending += 1;
+                const double deadline = t_now + offs;          // MRRL.PY:217
+                const bool fresh = r_rank[dec] < 0;            // broadcast read, before any lane updates
+                const float q_now = (float)r_queue[dec];
+                if (sl == 0) {
+                    if (fresh) {                                // MRRL.PY:361
+                        r_rank[dec] = (int8_t)n_pending;
+                        r_wl[dec] = wl; r_data[dec] = data; r_ddl[dec] = deadline;
+                    } else r_queue[dec] += 1;                  // MRRL.PY:359
+                }
+                if (fresh) {                                    // _get_obs, MRRL.PY:307-324
+                    const double rem = deadline - t_now;
+                    for (int c = sl; c < w; c += LPE) {
+                        float v;
+                        if (c == 0) v = s_ratio[dec];
+                        else if (c == 1) v = q_now;
+                        else if (c == 2) v = (float)data;
+                        else if (c == 3) v = (float)wl;
+                        else if (c == 4) v = (float)(rem > 0 ? rem : 0.0);
+                        else { const int i = c - 5; v = s_ratio[i < dec ? i : i + 1]; }
+                        s_obs[dec * w + c] = v;
+                    }
+                    n_pending += 1;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 
     STAMP(9);
@@ -561,26 +665,29 @@ __global__ __launch_bounds__(256, 6) void env_kernel(const EnvParams p, unsigned
             r_queue[sl] = q > 0 ? q : 0;
         }
     }
-    const uint64_t act_bits = group_bits<LPE>(__ballot(agent && r_rank[sl] >= 0), g);
+    const int rank_out = agent ? (int)r_rank[sl] : -1;
+    const uint64_t act_bits = group_bits<LPE>(__ballot(rank_out >= 0), g);
     if (out.n_draws) {
         int d = draws_lane;
         for (int m = LPE / 2; m > 0; m >>= 1) d += __shfl_xor(d, m, LPE);
+        // once per environment: rate (random mode), window (step only), arrival count, 4 per arrival
+        const int draws_env = (p.rate_mode == 2 ? 1 : 0) + (RESET ? 0 : 1) + 1 + 4 * n_new;
         if (valid && sl == 0) out.n_draws[env] = d + draws_env;
     }
     if (valid && sl == 0) {
         if constexpr (!RESET) {
             r_scal[S_TIME] = t_now + window;               // delta_t > 0 always: dt_min > 0
             r_scal[S_ELAPSED] = r_scal[S_ELAPSED] + window;
-            r_int[I_STEP] = step_no;
+            r_int[I_STEP] = (int32_t)step_no;
             if (out.reward) out.reward[env] = reward;
             if (out.emitted) out.emitted[env] = n_pending > 0;
             if (out.reward_seen) out.reward_seen[env] = n_pending > 0 ? reward : 0.0;
-            if (out.done) out.done[env] = step_no >= p.horizon;
+            if (out.done) out.done[env] = (int32_t)step_no >= p.horizon;
         }
         r_int[I_PENDING] = n_pending;
         out.active[env] = act_bits;
     }
-    if (agent && out.rank) out.rank[env * n + sl] = r_rank[sl];
+    if (agent && out.rank) out.rank[env * n + sl] = (int8_t)rank_out;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -692,6 +799,8 @@ struct em_handle {
     int64_t lat_cap = 0;
     int lanes = 0;                 // lanes per environment in use
     int lanes_forced = 0;
+    int wg_waves = 8;              // wavefronts per workgroup: wg_waves - 1 workers + 1 scalar
+    int32_t step = 0;              // steps taken since the last reset
     unsigned char* d_state = nullptr;
     EnvConst* d_const = nullptr;
     double* d_lat_log = nullptr;
@@ -743,10 +852,9 @@ EnvParams make_params(const em_handle* h, int lanes)
     const int epw = 64 / lanes;
     int wb = epw * p.rec_bytes;
     wb += (epw * p.obs_floats * 4 + 15) & ~15;
-    wb += (3 * p.n + 1) * 8;       // capacity, 1/capacity and 1/k tables
-    wb += 2 * epw * p.n * 8;       // latencies, energies of the step
-    wb += (epw * p.n * 4 + 7) & ~7;   // load ratios
-    wb += epw * PRE_LANES * 20;    // pre-drawn environment-level random numbers
+    wb += 2 * epw * (p.n < 8 ? 8 : p.n) * 8;   // latencies, energies of the step
+    wb += epw * 8;                 // acting-rank masks
+    wb += 2 * epw * p.n * 4;       // load ratios, first arrival per decider
     p.wave_bytes = (wb + 15) & ~15;
     // _get_current_epsilon, MRRL.PY:249-256
     double eps = 0.0;
@@ -759,6 +867,7 @@ EnvParams make_params(const em_handle* h, int lanes)
     p.eps = eps;
     p.seed_lo = (uint32_t)h->seed; p.seed_hi = (uint32_t)(h->seed >> 32);
     p.episode = h->episode;
+    p.step_no = h->step + 1;
     p.env_offset = (uint32_t)h->env_offset;
     p.n_envs = h->n_envs;
     p.lat_cap = h->lat_cap;
@@ -772,14 +881,15 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     const int lanes = h->lanes;
     const EnvParams p = make_params(h, lanes);
     const int epw = 64 / lanes;
-    const int64_t waves = (h->n_envs + epw - 1) / epw;
-    const int64_t blocks = (waves + 3) / 4;
-    const size_t lds = (size_t)p.wave_bytes * 4;
+    const int n_work = h->wg_waves - 1;
+    const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
+    const int64_t blocks = (h->n_envs + epb - 1) / epb;
+    const size_t lds = (size_t)p.wave_bytes * n_work + 64 * 12;
     if (lds > 160 * 1024) return em::fail(EM_ERR_INVALID, "n_nodes too large for the LDS tile (%zu bytes)", lds);
     em_tape tp;
     std::memset(&tp, 0, sizeof tp);
     if (tape) tp = *tape;
-    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 grid((unsigned)blocks), block(64 * h->wg_waves);
 #define EM_LAUNCH(L)                                                                                              \
     hipLaunchKernelGGL((env_kernel<L, TAPE, RESET>), grid, block, lds, s, p, h->d_state, h->d_const, placement,     \
                        resource, tp, *out, h->d_lat_log, h->d_err)
@@ -895,6 +1005,7 @@ int em_reset(em_handle* h, const em_tape* tape, int has_seed, uint64_t seed, con
     if (has_seed) { h->seed = seed; h->episode = 0; }
     h->episode += 1;
     h->was_reset = true;
+    h->step = 0;
     hipStream_t s = (hipStream_t)stream;
     return tape ? launch_env<true, true>(h, nullptr, nullptr, tape, out, s)
                 : launch_env<false, true>(h, nullptr, nullptr, nullptr, out, s);
@@ -914,6 +1025,7 @@ int em_step(em_handle* h, const int32_t* placement, const float* resource, const
     rc = tape ? launch_env<true, false>(h, placement, resource, tape, out, s)
               : launch_env<false, false>(h, placement, resource, nullptr, out, s);
     if (rc) return rc;
+    h->step += 1;
     if (!h->explore_off) h->explore_counter += 1;   // MRRL.PY:467-468
     return EM_OK;
 }
@@ -953,6 +1065,15 @@ int em_set_lanes_per_env(em_handle* h, int lanes)
     if ((lanes != 16 && lanes != 32 && lanes != 64) || lanes < h->cfg.n_nodes)
         return em::fail(EM_ERR_INVALID, "lanes per env must be 16, 32 or 64 and >= n_nodes");
     h->lanes = lanes;
+    return EM_OK;
+}
+
+int em_set_workgroup_waves(em_handle* h, int waves)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "null handle");
+    if (waves == 0) waves = 8;
+    if (waves < 2 || waves * 64 > EM_ENV_MAX_THREADS) return em::fail(EM_ERR_INVALID, "workgroup wavefronts must be 2..%d", EM_ENV_MAX_THREADS / 64);
+    h->wg_waves = waves;
     return EM_OK;
 }
 

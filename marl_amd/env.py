@@ -138,6 +138,10 @@ class BatchedEdgeSimGym:
     def set_lanes_per_env(self, lanes: int):
         _lib.check(self._L.em_set_lanes_per_env(self._h, int(lanes)))
 
+    def set_workgroup_waves(self, waves: int):
+        """Wavefronts per workgroup of the step kernel (waves - 1 workers + 1 scalar); tuning only."""
+        _lib.check(self._L.em_set_workgroup_waves(self._h, int(waves)))
+
     @property
     def record_bytes(self) -> int:
         return int(self._L.em_record_bytes(self._h))

@@ -137,16 +137,18 @@ def test_lane_packings_agree_and_absent_actions():
     for pl, rsrc in acts:
         o, r, e, d = ref.step(pl, rsrc)
         ref_trace.append((o.copy(), r.copy()))
-    for lanes in (16, 32, 64):
+    for lanes, waves in ((16, 8), (32, 8), (64, 8), (16, 2), (16, 5), (32, 3)):
         env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=5)
         env.set_lanes_per_env(lanes)
+        env.set_workgroup_waves(waves)
         env.reset()
         for (pl, rsrc), (ro, rr) in zip(acts, ref_trace):
             obs, rew, done, _, info = env.step(torch.as_tensor(pl).cuda(), torch.as_tensor(rsrc).cuda())
             assert np.array_equal(obs.cpu().numpy(), ro) and np.array_equal(info["reward_raw"].cpu().numpy(), rr)
         outs.append(env.get_state())
     for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k])
+        for other in outs[1:]:
+            assert np.array_equal(outs[0][k], other[k])
 
 
 def test_properties_at_65536_envs():

@@ -23,6 +23,7 @@ int main(int argc, char** argv)
     c.initial_epsilon = 1.0; c.final_epsilon = 0.05; c.decay_steps = 1000000;
     em_handle* h = nullptr;
     if (em_create(&c, B, 0, 7, 0, 0, &h)) { printf("create: %s\n", em_last_error()); return 1; }
+    if (argc > 3 && em_set_workgroup_waves(h, atoi(argv[3]))) { printf("waves: %s\n", em_last_error()); return 1; }
     const int n = 10;
     std::vector<int32_t> pl(B * n);
     std::vector<float> rs(B * n);
@@ -49,19 +50,24 @@ int main(int argc, char** argv)
     hipEventElapsedTime(&ms, e0, e1);
     printf("B=%lld explore=%d: %.2f us/step\n", (long long)B, explore, ms * 1e3 / K);
     unsigned long long st[16];
-    double acc[16] = {0};
+    const int seq[10] = {0, 1, 2, 3, 4, 5, 6, 9, 10, 11};
+    const char* names[10] = {"", "loads+philox+stage-in", "placement(par)", "chain", "reward", "(wait at barrier)",
+                             "arrivals(par)", "arrival tail", "decay/outputs", "stage-out"};
+    double acc[10] = {0}, sc[3] = {0};
     const int R = 20;
     for (int r = 0; r < R; ++r) {
         em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st, HIP_SYMBOL(em_stamps), sizeof st);
-        for (int i = 1; i < 12; ++i) acc[i] += (double)(st[i] - st[i - 1]);
+        for (int i = 1; i < 10; ++i) acc[i] += (double)(st[seq[i]] - st[seq[i - 1]]);
+        sc[0] += (double)((long long)(st[12] - st[0]));
+        sc[1] += (double)(st[13] - st[12]);
+        sc[2] += (double)(st[14] - st[13]);
     }
-    const char* names[12] = {"", "stage-in", "placement(par)", "chain", "reward", "pre-draw(philox A)", "rate", "dt/window",
-                             "poisson", "arrival loop", "decay/outputs", "stage-out"};
     double tot = 0;
-    for (int i = 1; i < 12; ++i) { printf("  %-20s %8.0f cycles\n", names[i], acc[i] / R); tot += acc[i] / R; }
-    printf("  %-20s %8.0f cycles (s_memtime ticks)\n", "total", tot);
+    for (int i = 1; i < 10; ++i) { printf("  %-22s %8.0f cycles\n", names[i], acc[i] / R); tot += acc[i] / R; }
+    printf("  %-22s %8.0f cycles (s_memtime ticks)\n", "worker total", tot);
+    printf("  scalar wavefront: starts %+.0f after worker 0, rate+window %.0f, poisson %.0f cycles\n", sc[0] / R, sc[1] / R, sc[2] / R);
     em_destroy(h);
     return 0;
 }
