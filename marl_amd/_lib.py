@@ -14,7 +14,7 @@ from .config import EmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class EmTape(C.Structure):
@@ -49,7 +49,7 @@ class EmRollout(C.Structure):
         (name, C.c_void_p) for name in (
             "ent_obs", "ent_action", "ent_logp", "ent_env", "ent_agent", "ent_adv", "ent_ret",
             "st_state", "st_value", "st_env", "st_first", "st_k",
-            "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "counters", "err_flag")]
+            "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "scan_scratch", "counters", "err_flag")]
 
 
 _lib = None

@@ -87,9 +87,25 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
     int64_t row_base = 0, n_rows = a.n_rows;
     if (a.dyn) { row_base = a.dyn[0]; n_rows = a.dyn[1]; }
     const int64_t n_tiles = (n_rows + 15) >> 4;
+    if ((int64_t)blockIdx.x * 4 >= n_tiles) return;    // whole workgroup idle (uniform: safe before the barrier)
+
+    // ---- weights: HBM/L2 -> LDS once per workgroup (coalesced), LDS -> register fragments once per wavefront
+    extern __shared__ __align__(16) float lds[];
+    constexpr int K1P = KU * 16;
+    constexpr int S1 = (K1P + 2) | 2;                 // row strides of the form 2*odd: conflict-free fragment reads
+    constexpr int S2 = 66;
+    float* W1s = lds;                                 // [64][S1]
+    float* W2s = W1s + HID * S1;                      // [64][S2]
+    float* W3s = W2s + HID * S2;                      // [16][S2] (rows >= O are zero)
+    for (int i = threadIdx.x; i < HID * K1P; i += 256) {
+        const int r = i / K1P, k = i - r * K1P;
+        W1s[r * S1 + k] = k < K1 ? a.net.w1[r * K1 + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < HID * HID; i += 256) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
+    for (int i = threadIdx.x; i < 16 * HID; i += 256) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
+    __syncthreads();
     if ((int64_t)blockIdx.x * 4 + wave >= n_tiles) return;
 
-    // ---- weight fragments (A operands) and biases, resident in registers ----------------------------
     float a1[4][KU * 4], a2[4][16], a3[16];
     f32x4 bias1[4], bias2[4], bias3;
 #pragma unroll
@@ -97,12 +113,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #pragma unroll
         for (int u = 0; u < KU; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 16 * u + 4 * q + r;
-                a1[t][u * 4 + r] = k < K1 ? a.net.w1[(16 * t + c) * K1 + k] : 0.0f;
-            }
+            for (int r = 0; r < 4; ++r) a1[t][u * 4 + r] = W1s[(16 * t + c) * S1 + 16 * u + 4 * q + r];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) a2[t][s] = a.net.w2[(16 * t + c) * HID + 16 * (s >> 2) + 4 * q + (s & 3)];
+        for (int s = 0; s < 16; ++s) a2[t][s] = W2s[(16 * t + c) * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             bias1[t][r] = a.net.b1[16 * t + 4 * q + r];
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         }
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) a3[s] = c < O ? a.net.w3[c * HID + 16 * (s >> 2) + 4 * q + (s & 3)] : 0.0f;
+    for (int s = 0; s < 16; ++s) a3[s] = W3s[c * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
 
@@ -243,88 +256,146 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// trajectory indexing: exclusive scan of the per-environment acting-agent counts (one workgroup)
-// counters row t = {entry_base, n_entries, step_base, n_nonempty}; row t+1 bases are written here.
+// trajectory indexing and compaction (RolloutBuffer.add, MAPPOTrainer._store_transition).
+// Entries of a step are numbered in (environment, arrival rank) order, so the slot of an environment
+// is an exclusive prefix sum of the per-environment acting-agent counts.  Two launches, both parallel
+// over 1024-environment chunks and free of inter-workgroup waiting:
+//   rollout_count_kernel        chunk totals {entries | non-empty environments << 32}
+//   rollout_scan_compact_kernel chunk base = sum of the preceding chunk totals, scan inside the chunk,
+//                               then the chunk's wavefronts copy the state rows and entry rows.
+// counters row t = {entry_base, n_entries, step_base, n_nonempty}; the bases of row t+1 are written here.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rollout_index_kernel(int64_t B, int t, const uint64_t* __restrict__ active,
-                                                             int64_t* __restrict__ counters, uint8_t* __restrict__ k_tb,
-                                                             int32_t* __restrict__ first_tb, int32_t* __restrict__ srow,
-                                                             int64_t cap_e, int64_t cap_s, int32_t* __restrict__ err)
+constexpr int CHUNK = 1024;
+
+__global__ __launch_bounds__(256) void rollout_count_kernel(int64_t B, const uint64_t* __restrict__ active,
+                                                            unsigned long long* __restrict__ chunk_tot)
 {
-    __shared__ unsigned long long wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
-    unsigned long long running = 0;   // low 32: entries, high 32: non-empty environments
-    for (int64_t p = 0; p < B; p += 1024) {
-        const int64_t b = p + tid;
-        const unsigned long long m = b < B ? active[b] : 0ull;
-        const unsigned long long k = (unsigned long long)__popcll(m);
-        const unsigned long long v = k | ((k ? 1ull : 0ull) << 32);
-        unsigned long long inc = v;
+    __shared__ unsigned long long ws[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * CHUNK;
+    unsigned long long v = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        unsigned long long woff = 0, btot = 0;
+    for (int i = 0; i < CHUNK / 256; ++i) {
+        const int64_t b = b0 + i * 256 + threadIdx.x;
+        const unsigned long long k = b < B ? (unsigned long long)__popcll(active[b]) : 0ull;
+        v += k | ((k ? 1ull : 0ull) << 32);
+    }
 #pragma unroll
-        for (int wv = 0; wv < 16; ++wv) {
-            const unsigned long long x = wave_tot[wv];
-            if (wv < wave) woff += x;
-            btot += x;
-        }
-        __syncthreads();
-        const unsigned long long excl = running + woff + inc - v;
-        if (b < B) {
-            k_tb[b] = (uint8_t)k;
-            first_tb[b] = (int32_t)(e_base + (int64_t)(excl & 0xffffffffull));
-            srow[b] = k ? (int32_t)(s_base + (int64_t)(excl >> 32)) : -1;
-        }
-        running += btot;
-    }
-    if (tid == 0) {
-        int64_t ne = (int64_t)(running & 0xffffffffull), ns = (int64_t)(running >> 32);
-        if (e_base + ne > cap_e || s_base + ns > cap_s) { atomicOr(err, 8); ne = 0; ns = 0; }
-        counters[4 * t + 1] = ne;
-        counters[4 * t + 3] = ns;
-        counters[4 * (t + 1) + 0] = e_base + ne;
-        counters[4 * (t + 1) + 2] = s_base + ns;
-    }
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) ws[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// one wavefront per environment: copies the dense state row block and the acting agents' rows
-__global__ __launch_bounds__(256) void rollout_compact_kernel(int64_t B, int n, int t, const float* __restrict__ obs,
-                                                              const int8_t* __restrict__ rank,
-                                                              const int64_t* __restrict__ counters,
-                                                              const uint8_t* __restrict__ k_tb,
-                                                              const int32_t* __restrict__ first_tb,
-                                                              const int32_t* __restrict__ srow, float* __restrict__ ent_obs,
-                                                              int32_t* __restrict__ ent_env, int8_t* __restrict__ ent_agent,
-                                                              float* __restrict__ st_state, int32_t* __restrict__ st_env,
-                                                              int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k)
+__global__ __launch_bounds__(1024) void rollout_scan_compact_kernel(
+    int64_t B, int n, int t, const uint64_t* __restrict__ active, const int8_t* __restrict__ rank,
+    const float* __restrict__ obs, const unsigned long long* __restrict__ chunk_tot, int n_chunks,
+    int64_t* __restrict__ counters, uint8_t* __restrict__ k_tb, int32_t* __restrict__ first_tb, int32_t* __restrict__ srow,
+    int64_t cap_e, int64_t cap_s, int32_t* __restrict__ err, float* __restrict__ ent_obs, int32_t* __restrict__ ent_env,
+    int8_t* __restrict__ ent_agent, float* __restrict__ st_state, int32_t* __restrict__ st_env,
+    int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned long long red[2][16];
+    __shared__ unsigned long long wave_tot[16];
+    __shared__ int32_t s_first[CHUNK];
+    __shared__ uint16_t s_list[CHUNK];
+    __shared__ uint8_t s_k[CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
+
+    // ---- totals of the preceding chunks and of the whole step ----------------------------------------
+    unsigned long long pre = 0, all = 0;
+    for (int i = tid; i < n_chunks; i += 1024) {
+        const unsigned long long x = chunk_tot[i];
+        all += x;
+        if (i < (int)blockIdx.x) pre += x;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d); all += __shfl_xor(all, d); }
+    if (lane == 0) { red[0][wave] = pre; red[1][wave] = all; }
+
+    // ---- scan inside the chunk -------------------------------------------------------------------------
+    const int64_t b = (int64_t)blockIdx.x * CHUNK + tid;
+    const unsigned long long k = b < B ? (unsigned long long)__popcll(active[b]) : 0ull;
+    const unsigned long long v = k | ((k ? 1ull : 0ull) << 32);
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    pre = 0; all = 0;
+    unsigned long long woff = 0, ctot = 0;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) {
+        pre += red[0][wv];
+        all += red[1][wv];
+        const unsigned long long x = wave_tot[wv];
+        if (wv < wave) woff += x;
+        ctot += x;
+    }
+    const int64_t ne = (int64_t)(all & 0xffffffffull), ns = (int64_t)(all >> 32);
+    const bool overflow = e_base + ne > cap_e || s_base + ns > cap_s;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (overflow) atomicOr(err, 8);
+        counters[4 * t + 1] = overflow ? 0 : ne;
+        counters[4 * t + 3] = overflow ? 0 : ns;
+        counters[4 * (t + 1) + 0] = e_base + (overflow ? 0 : ne);
+        counters[4 * (t + 1) + 2] = s_base + (overflow ? 0 : ns);
+    }
+    const unsigned long long excl = woff + inc - v;                    // within the chunk
+    const int64_t first = e_base + (int64_t)((pre + excl) & 0xffffffffull);
+    const int64_t sr0 = s_base + (int64_t)(pre >> 32);                 // step row of the chunk's first non-empty env
+    const int li = (int)(excl >> 32);                                  // index among the chunk's non-empty envs
+    if (b < B) {
+        k_tb[b] = (uint8_t)k;
+        first_tb[b] = (int32_t)first;
+        srow[b] = k ? (int32_t)(sr0 + li) : -1;
+    }
+    if (overflow) return;
+    s_first[tid] = (int32_t)first;
+    s_k[tid] = (uint8_t)k;
+    if (k) s_list[li] = (uint16_t)tid;
+    __syncthreads();
+
+    // ---- compaction: one wavefront per non-empty environment of the chunk ----------------------------------
+    const int n_loc = (int)(ctot >> 32);
     const int w = n + 4, sw = n * w;
-    if (counters[4 * t + 1] == 0) return;     // nothing acted this step (or capacity overflow flagged)
-    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
-        const int k = k_tb[b];
-        if (k == 0) continue;
-        const int64_t first = first_tb[b], sr = srow[b];
-        const float* src = obs + b * sw;
-        for (int i = lane; i < sw; i += 64) {
-            const float v = src[i];
-            st_state[sr * sw + i] = v;
-            const int ag = i / w, col = i - ag * w;
-            const int r = rank[b * n + ag];
-            if (r >= 0) ent_obs[(first + r) * w + col] = v;
+    const bool vec = (sw & 3) == 0;   // rows are 16-byte multiples (obs base is 16-byte aligned by contract)
+    for (int j = wave; j < n_loc; j += 16) {
+        const int i = s_list[j];
+        const int64_t bb = (int64_t)blockIdx.x * CHUNK + i;
+        const int64_t f = s_first[i], sr = sr0 + j;
+        const float* src = obs + bb * sw;
+        float* dst = st_state + sr * sw;
+        if (vec) {
+            for (int q = lane; q < (sw >> 2); q += 64) {
+                const float4 x = reinterpret_cast<const float4*>(src)[q];
+                reinterpret_cast<float4*>(dst)[q] = x;
+                const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = 4 * q + c, ag = e / w, col = e - ag * w;
+                    const int r = rank[bb * n + ag];
+                    if (r >= 0) ent_obs[(f + r) * w + col] = xs[c];
+                }
+            }
+        } else {
+            for (int e = lane; e < sw; e += 64) {
+                const float x = src[e];
+                dst[e] = x;
+                const int ag = e / w, col = e - ag * w;
+                const int r = rank[bb * n + ag];
+                if (r >= 0) ent_obs[(f + r) * w + col] = x;
+            }
         }
         if (lane < n) {
-            const int r = rank[b * n + lane];
-            if (r >= 0) { ent_env[first + r] = (int32_t)b; ent_agent[first + r] = (int8_t)lane; }
+            const int r = rank[bb * n + lane];
+            if (r >= 0) { ent_env[f + r] = (int32_t)bb; ent_agent[f + r] = (int8_t)lane; }
         }
-        if (lane == 0) { st_env[sr] = (int32_t)b; st_first[sr] = (int32_t)first; st_k[sr] = (uint8_t)k; }
+        if (lane == 0) { st_env[sr] = (int32_t)bb; st_first[sr] = (int32_t)f; st_k[sr] = s_k[i]; }
     }
 }
 
@@ -344,11 +415,13 @@ int launch_fwd(const FwdArgs& fa, int64_t max_rows, hipStream_t s)
     const int ku = (fa.net.in_dim + 15) / 16;
     int64_t tiles = (max_rows + 15) / 16;
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 1024) blocks = 1024;     // persistent: each wavefront keeps its weight fragments and strides over tiles
-    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;       // persistent, one workgroup per CU: the weights are staged once per workgroup
+    if (blocks < 1) blocks = 1;           // and each wavefront keeps its fragments while it strides over tiles
     const dim3 grid((unsigned)blocks), block(256);
+    const int s1 = (ku * 16 + 2) | 2;
+    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * 66 + 16 * 66);
 #define EM_FWD(KU_)                                                                                   \
-    case KU_: hipLaunchKernelGGL((mlp3_fwd_kernel<KU_, MODE>), grid, block, 0, s, fa); break
+    case KU_: hipLaunchKernelGGL((mlp3_fwd_kernel<KU_, MODE>), grid, block, lds, s, fa); break
     switch (ku) {
         EM_FWD(1); EM_FWD(2); EM_FWD(3); EM_FWD(4); EM_FWD(5); EM_FWD(6); EM_FWD(7); EM_FWD(8); EM_FWD(9);
         default: return em::fail(EM_ERR_INVALID, "mlp3: unsupported in_dim");
@@ -378,15 +451,19 @@ int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, co
 {
     if (!ro || !active || !rank || !obs) return em::fail(EM_ERR_INVALID, "em_rollout_index: null argument");
     if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_rollout_index: step %d outside [0,%d)", t, ro->horizon);
+    if (!ro->scan_scratch) return em::fail(EM_ERR_INVALID, "em_rollout_index: scan_scratch is required");
+    if (ro->n_nodes > 64) return em::fail(EM_ERR_INVALID, "em_rollout_index: n_nodes must be <= 64");
+    if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0 || (reinterpret_cast<uintptr_t>(ro->st_state) & 15) != 0)
+        return em::fail(EM_ERR_INVALID, "em_rollout_index: obs and st_state must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int64_t B = ro->n_envs;
-    hipLaunchKernelGGL(rollout_index_kernel, dim3(1), dim3(1024), 0, s, B, t, active, ro->counters, ro->k_tb + (int64_t)t * B,
-                       ro->first_tb + (int64_t)t * B, ro->srow, ro->capacity_entries, ro->capacity_steps, ro->err_flag);
-    int64_t blocks = (B + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(rollout_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, B, ro->n_nodes, t, obs, rank,
-                       ro->counters, ro->k_tb + (int64_t)t * B, ro->first_tb + (int64_t)t * B, ro->srow, ro->ent_obs,
-                       ro->ent_env, ro->ent_agent, ro->st_state, ro->st_env, ro->st_first, ro->st_k);
+    const int64_t chunks = (B + CHUNK - 1) / CHUNK;
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(ro->scan_scratch);
+    hipLaunchKernelGGL(rollout_count_kernel, dim3((unsigned)chunks), dim3(256), 0, s, B, active, tot);
+    hipLaunchKernelGGL(rollout_scan_compact_kernel, dim3((unsigned)chunks), dim3(1024), 0, s, B, ro->n_nodes, t, active, rank,
+                       obs, tot, (int)chunks, ro->counters, ro->k_tb + (int64_t)t * B, ro->first_tb + (int64_t)t * B, ro->srow,
+                       ro->capacity_entries, ro->capacity_steps, ro->err_flag, ro->ent_obs, ro->ent_env, ro->ent_agent,
+                       ro->st_state, ro->st_env, ro->st_first, ro->st_k);
     return em::hip_check(hipGetLastError(), "rollout index/compact launch");
 }
 
