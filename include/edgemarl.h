@@ -171,7 +171,7 @@ typedef struct em_rollout {
     uint8_t *k_tb;         /* [T][B] acting agents                                                */
     int32_t *first_tb;     /* [T][B] first entry                                                  */
     int32_t *srow;         /* [B]    scratch: step row of the current step or -1                  */
-    int64_t *scan_scratch; /* [ceil(B/1024)] scratch of em_rollout_index                          */
+    int64_t *scan_scratch; /* [ceil(B/256)] scratch of em_rollout_index                           */
     int64_t *counters;     /* [T+1][4] {entry_base, n_entries, step_base, n_steps}; row 0 zeroed by the caller */
     int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller */
 } em_rollout;

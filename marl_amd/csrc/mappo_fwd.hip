@@ -97,12 +97,36 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
     float* W1s = lds;                                 // [64][S1]
     float* W2s = W1s + HID * S1;                      // [64][S2]
     float* W3s = W2s + HID * S2;                      // [16][S2] (rows >= O are zero)
-    for (int i = threadIdx.x; i < HID * K1P; i += 256) {
-        const int r = i / K1P, k = i - r * K1P;
-        W1s[r * S1 + k] = k < K1 ? a.net.w1[r * K1 + k] : 0.0f;
+    // fixed trip counts, fully unrolled in batches: the loads of a batch are in flight together
+    {
+        constexpr int N1 = HID * K1P / 256, N2 = HID * HID / 256, N3 = 16 * HID / 256;
+        float v2[N2], v3[N3];
+#pragma unroll
+        for (int j = 0; j < N2; ++j) v2[j] = a.net.w2[j * 256 + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < N3; ++j) {
+            const int i = j * 256 + threadIdx.x;
+            v3[j] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < N1; j0 += 12) {
+            float v1[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int i = (j0 + j) * 256 + threadIdx.x, r = i / K1P, k = i - r * K1P;
+                v1[j] = (j0 + j < N1 && k < K1) ? a.net.w1[r * K1 + k] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int i = (j0 + j) * 256 + threadIdx.x, r = i / K1P, k = i - r * K1P;
+                if (j0 + j < N1) W1s[r * S1 + k] = v1[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N2; ++j) { const int i = j * 256 + threadIdx.x; W2s[(i >> 6) * S2 + (i & 63)] = v2[j]; }
+#pragma unroll
+        for (int j = 0; j < N3; ++j) { const int i = j * 256 + threadIdx.x; W3s[(i >> 6) * S2 + (i & 63)] = v3[j]; }
     }
-    for (int i = threadIdx.x; i < HID * HID; i += 256) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
-    for (int i = threadIdx.x; i < 16 * HID; i += 256) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
     __syncthreads();
     if ((int64_t)blockIdx.x * 4 + wave >= n_tiles) return;
 
@@ -259,35 +283,40 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 // trajectory indexing and compaction (RolloutBuffer.add, MAPPOTrainer._store_transition).
 // Entries of a step are numbered in (environment, arrival rank) order, so the slot of an environment
 // is an exclusive prefix sum of the per-environment acting-agent counts.  Two launches, both parallel
-// over 1024-environment chunks and free of inter-workgroup waiting:
+// over 256-environment chunks and free of inter-workgroup waiting:
 //   rollout_count_kernel        chunk totals {entries | non-empty environments << 32}
 //   rollout_scan_compact_kernel chunk base = sum of the preceding chunk totals, scan inside the chunk,
 //                               then the chunk's wavefronts copy the state rows and entry rows.
 // counters row t = {entry_base, n_entries, step_base, n_nonempty}; the bases of row t+1 are written here.
 // ------------------------------------------------------------------------------------------------
-constexpr int CHUNK = 1024;
+#ifndef EM_SCAN_CHUNK
+#define EM_SCAN_CHUNK 256
+#endif
+#ifndef EM_SCAN_UNROLL
+#define EM_SCAN_UNROLL 4
+#endif
+constexpr int CHUNK = EM_SCAN_CHUNK;    // environments per workgroup of the two kernels
 
-__global__ __launch_bounds__(256) void rollout_count_kernel(int64_t B, const uint64_t* __restrict__ active,
+__global__ __launch_bounds__(CHUNK) void rollout_count_kernel(int64_t B, const uint64_t* __restrict__ active,
                                                             unsigned long long* __restrict__ chunk_tot)
 {
-    __shared__ unsigned long long ws[4];
+    __shared__ unsigned long long ws[CHUNK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * CHUNK;
-    unsigned long long v = 0;
-#pragma unroll
-    for (int i = 0; i < CHUNK / 256; ++i) {
-        const int64_t b = b0 + i * 256 + threadIdx.x;
-        const unsigned long long k = b < B ? (unsigned long long)__popcll(active[b]) : 0ull;
-        v += k | ((k ? 1ull : 0ull) << 32);
-    }
+    const int64_t b = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    const unsigned long long k = b < B ? (unsigned long long)__popcll(active[b]) : 0ull;
+    unsigned long long v = k | ((k ? 1ull : 0ull) << 32);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
     if (lane == 0) ws[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < CHUNK / 64; ++i) tot += ws[i];
+        chunk_tot[blockIdx.x] = tot;
+    }
 }
 
-__global__ __launch_bounds__(1024) void rollout_scan_compact_kernel(
+__global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     int64_t B, int n, int t, const uint64_t* __restrict__ active, const int8_t* __restrict__ rank,
     const float* __restrict__ obs, const unsigned long long* __restrict__ chunk_tot, int n_chunks,
     int64_t* __restrict__ counters, uint8_t* __restrict__ k_tb, int32_t* __restrict__ first_tb, int32_t* __restrict__ srow,
@@ -295,17 +324,18 @@ __global__ __launch_bounds__(1024) void rollout_scan_compact_kernel(
     int8_t* __restrict__ ent_agent, float* __restrict__ st_state, int32_t* __restrict__ st_env,
     int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k)
 {
-    __shared__ unsigned long long red[2][16];
-    __shared__ unsigned long long wave_tot[16];
+    __shared__ unsigned long long red[2][CHUNK / 64];
+    __shared__ unsigned long long wave_tot[CHUNK / 64];
     __shared__ int32_t s_first[CHUNK];
     __shared__ uint16_t s_list[CHUNK];
     __shared__ uint8_t s_k[CHUNK];
+    __shared__ int8_t s_rank[CHUNK * 64];       // arrival ranks of the chunk (n <= 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
 
     // ---- totals of the preceding chunks and of the whole step ----------------------------------------
     unsigned long long pre = 0, all = 0;
-    for (int i = tid; i < n_chunks; i += 1024) {
+    for (int i = tid; i < n_chunks; i += CHUNK) {
         const unsigned long long x = chunk_tot[i];
         all += x;
         if (i < (int)blockIdx.x) pre += x;
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(1024) void rollout_scan_compact_kernel(
     pre = 0; all = 0;
     unsigned long long woff = 0, ctot = 0;
 #pragma unroll
-    for (int wv = 0; wv < 16; ++wv) {
+    for (int wv = 0; wv < CHUNK / 64; ++wv) {
         pre += red[0][wv];
         all += red[1][wv];
         const unsigned long long x = wave_tot[wv];
@@ -360,42 +390,73 @@ __global__ __launch_bounds__(1024) void rollout_scan_compact_kernel(
     if (k) s_list[li] = (uint16_t)tid;
     __syncthreads();
 
-    // ---- compaction: one wavefront per non-empty environment of the chunk ----------------------------------
+    // ---- compaction: element-parallel over the chunk's non-empty state rows ---------------------------------
+    // (independent iterations, unrolled: several row segments are in flight per lane; destination contiguous)
     const int n_loc = (int)(ctot >> 32);
     const int w = n + 4, sw = n * w;
-    const bool vec = (sw & 3) == 0;   // rows are 16-byte multiples (obs base is 16-byte aligned by contract)
-    for (int j = wave; j < n_loc; j += 16) {
-        const int i = s_list[j];
-        const int64_t bb = (int64_t)blockIdx.x * CHUNK + i;
-        const int64_t f = s_first[i], sr = sr0 + j;
-        const float* src = obs + bb * sw;
-        float* dst = st_state + sr * sw;
-        if (vec) {
-            for (int q = lane; q < (sw >> 2); q += 64) {
-                const float4 x = reinterpret_cast<const float4*>(src)[q];
-                reinterpret_cast<float4*>(dst)[q] = x;
-                const float xs[4] = {x.x, x.y, x.z, x.w};
+    const int64_t cb = (int64_t)blockIdx.x * CHUNK;
+    for (int i = tid; i < CHUNK * n; i += CHUNK) s_rank[i] = (cb * n + i) < B * n ? rank[cb * n + i] : (int8_t)-1;
+    __syncthreads();
+    const uint32_t magic_w = (uint32_t)((0x100000000ull + (uint32_t)w - 1u) / (uint32_t)w);   // e / w for e < 2^16
+    if ((sw & 3) == 0) {   // rows are 16-byte multiples (obs and st_state bases are 16-byte aligned by contract)
+        const int v4 = sw >> 2, total = n_loc * v4;
+        const uint32_t magic_v = (uint32_t)((0x100000000ull + (uint32_t)v4 - 1u) / (uint32_t)v4);
+        constexpr int U = EM_SCAN_UNROLL;
+        for (int e0 = tid; e0 < total; e0 += CHUNK * U) {
+            float4 x[U];
+            int jj[U], qq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * CHUNK;
+                jj[u] = -1;
+                if (e < total) {
+                    const int j = (int)__umulhi((uint32_t)e, magic_v), q = e - j * v4;
+                    jj[u] = j; qq[u] = q;
+                    x[u] = reinterpret_cast<const float4*>(obs + (cb + s_list[j]) * sw)[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (jj[u] < 0) continue;
+                const int j = jj[u], q = qq[u], i = s_list[j];
+                reinterpret_cast<float4*>(st_state + (sr0 + j) * sw)[q] = x[u];
+                const int64_t f = s_first[i];
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int e = 4 * q + c, ag = e / w, col = e - ag * w;
-                    const int r = rank[bb * n + ag];
+                    const int e = 4 * q + c, ag = (int)__umulhi((uint32_t)e, magic_w), col = e - ag * w;
+                    const int r = s_rank[i * n + ag];
                     if (r >= 0) ent_obs[(f + r) * w + col] = xs[c];
                 }
             }
-        } else {
-            for (int e = lane; e < sw; e += 64) {
-                const float x = src[e];
-                dst[e] = x;
-                const int ag = e / w, col = e - ag * w;
-                const int r = rank[bb * n + ag];
-                if (r >= 0) ent_obs[(f + r) * w + col] = x;
-            }
         }
-        if (lane < n) {
-            const int r = rank[bb * n + lane];
-            if (r >= 0) { ent_env[f + r] = (int32_t)bb; ent_agent[f + r] = (int8_t)lane; }
+    } else {
+        const int total = n_loc * sw;
+        const uint32_t magic_s = (uint32_t)((0x100000000ull + (uint32_t)sw - 1u) / (uint32_t)sw);
+        for (int e = tid; e < total; e += CHUNK) {
+            const int j = (int)__umulhi((uint32_t)e, magic_s), q = e - j * sw, i = s_list[j];
+            const float x = obs[(cb + i) * sw + q];
+            st_state[(sr0 + j) * sw + q] = x;
+            const int ag = (int)__umulhi((uint32_t)q, magic_w), col = q - ag * w;
+            const int r = s_rank[i * n + ag];
+            if (r >= 0) ent_obs[(s_first[i] + r) * w + col] = x;
         }
-        if (lane == 0) { st_env[sr] = (int32_t)bb; st_first[sr] = (int32_t)f; st_k[sr] = s_k[i]; }
+    }
+    // per-entry and per-step index rows
+    for (int e = tid; e < CHUNK * n; e += CHUNK) {
+        const int i = (int)__umulhi((uint32_t)e, (uint32_t)((0x100000000ull + (uint32_t)n - 1u) / (uint32_t)n)), ag = e - i * n;
+        const int r = s_rank[e];
+        if (r >= 0 && s_k[i]) {
+            const int64_t f = s_first[i];
+            ent_env[f + r] = (int32_t)(cb + i);
+            ent_agent[f + r] = (int8_t)ag;
+        }
+    }
+    for (int j = tid; j < n_loc; j += CHUNK) {
+        const int i = s_list[j];
+        st_env[sr0 + j] = (int32_t)(cb + i);
+        st_first[sr0 + j] = s_first[i];
+        st_k[sr0 + j] = s_k[i];
     }
 }
 
@@ -459,8 +520,8 @@ int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, co
     const int64_t B = ro->n_envs;
     const int64_t chunks = (B + CHUNK - 1) / CHUNK;
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(ro->scan_scratch);
-    hipLaunchKernelGGL(rollout_count_kernel, dim3((unsigned)chunks), dim3(256), 0, s, B, active, tot);
-    hipLaunchKernelGGL(rollout_scan_compact_kernel, dim3((unsigned)chunks), dim3(1024), 0, s, B, ro->n_nodes, t, active, rank,
+    hipLaunchKernelGGL(rollout_count_kernel, dim3((unsigned)chunks), dim3(CHUNK), 0, s, B, active, tot);
+    hipLaunchKernelGGL(rollout_scan_compact_kernel, dim3((unsigned)chunks), dim3(CHUNK), 0, s, B, ro->n_nodes, t, active, rank,
                        obs, tot, (int)chunks, ro->counters, ro->k_tb + (int64_t)t * B, ro->first_tb + (int64_t)t * B, ro->srow,
                        ro->capacity_entries, ro->capacity_steps, ro->err_flag, ro->ent_obs, ro->ent_env, ro->ent_agent,
                        ro->st_state, ro->st_env, ro->st_first, ro->st_k);

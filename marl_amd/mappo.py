@@ -186,7 +186,7 @@ class RolloutStorage:
             ent_agent=z(E, torch.int8), ent_adv=z(E, f32), ent_ret=z(E, f32),
             st_state=z((S, n * w), f32), st_value=z(S, f32), st_env=z(S, i32), st_first=z(S, i32), st_k=z(S, u8),
             reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), value_tb=z((T, B), f32), k_tb=z((T, B), u8),
-            first_tb=z((T, B), i32), srow=z(B, i32), scan_scratch=z((B + 1023) // 1024, torch.int64), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32))
+            first_tb=z((T, B), i32), srow=z(B, i32), scan_scratch=z((B + 63) // 64, torch.int64), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32))
         self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() for v in self.t.values()])
         self.steps_recorded = 0
 
