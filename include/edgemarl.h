@@ -106,6 +106,15 @@ int em_reset(em_handle *h, const em_tape *tape, int has_seed, uint64_t seed, con
 int em_step(em_handle *h, const int32_t *placement, const float *resource, const em_tape *tape,
             const em_step_out *out, void *stream);
 
+/* EdgeSimGym.step fed continuous action vectors (the non-dict branch of _convert_action, MRRL.PY:283-305):
+ * raw_actions [n_envs][n_nodes][n_nodes+1] float32; placement = 0 if all of the first n_nodes components are
+ * within 1e-8 of 0, else the first argmax; resource = float32(0.1 + 0.9*clip((x_last + 1)/2, 0, 1)) in float64. */
+int em_step_raw(em_handle *h, const float *raw_actions, const em_tape *tape, const em_step_out *out, void *stream);
+
+/* EdgeSimGym.step under the greedy baseline's policy (run_greedy_baseline, MRRL.PY:803-812): every acting
+ * agent targets argmin(nodes_load / cpu_caps) (first minimum) with the given resource share (reference 0.5). */
+int em_step_greedy(em_handle *h, float resource_share, const em_tape *tape, const em_step_out *out, void *stream);
+
 /* Episode metrics (MRRL.PY:470-504), out6 = device [n_envs][6] float64:
  * avg_latency_ms, p99_latency_ms (NaN without a latency log), avg_energy_J, violation_rate,
  * throughput_tps, load_balance_jain. */

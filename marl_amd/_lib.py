@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
     L.em_destroy.argtypes = [vp]
     L.em_reset.argtypes = [vp, C.POINTER(EmTape), i32, u64, C.POINTER(EmStepOut), vp]
     L.em_step.argtypes = [vp, vp, vp, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
+    L.em_step_raw.argtypes = [vp, vp, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
+    L.em_step_greedy.argtypes = [vp, C.c_float, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
     L.em_episode_metrics.argtypes = [vp, vp, vp]
     L.em_set_exploration.argtypes = [vp, i32, i64]
     L.em_get_exploration_counter.argtypes = [vp]
@@ -99,7 +101,7 @@ def lib() -> C.CDLL:
                  "em_ppo_critic_grad", "em_adam_step"):
         getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
-                 "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves"):
+                 "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves", "em_step_raw", "em_step_greedy"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -57,7 +57,9 @@ struct EnvParams {
     int32_t n, horizon, rate_mode, explore;
     int32_t rec_bytes, obs_floats, wave_bytes, pad0;
     double eps;
-    int32_t step_no, pad1;       // 1-based index of the step being taken (all environments of a handle move together)
+    int32_t step_no;
+    float greedy_share;          // resource share of the greedy policy (ACT_GREEDY)
+    // step_no: 1-based index of the step being taken (all environments of a handle move together)
     uint32_t seed_lo, seed_hi, episode, env_offset;
     int64_t n_envs, lat_cap;
 };
@@ -213,7 +215,13 @@ __device__ inline uint64_t group_bits(uint64_t ballot, int g)
 // (MRRL.PY:220-247,350-351).  That chain does not depend on the placements, so it runs beside the
 // workers' placement phase and is handed over through LDS at the workgroup's single barrier; run on the
 // workers it would be evaluated redundantly on all LPE lanes of every group.
-template <int LPE, bool TAPE, bool RESET>
+// ACT selects where the step's actions come from: ACT_DICT placement/resource arrays (the dict form of
+// MRRL.PY:280-281), ACT_RAW continuous vectors [n_envs][n][n+1] converted as _convert_action does
+// (MRRL.PY:283-305; passed through the `resource` pointer), ACT_GREEDY the greedy baseline's policy
+// (MRRL.PY:806-812): argmin of load/capacity by wavefront shuffles, fixed resource share.
+enum { ACT_DICT = 0, ACT_RAW = 1, ACT_GREEDY = 2 };
+
+template <int LPE, bool TAPE, bool RESET, int ACT>
 __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
                                                   const EnvConst* __restrict__ cc,
                                                   const int32_t* __restrict__ placement,
@@ -359,7 +367,23 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             cap_me = cc->cap[sl];
             icap_me = cc->inv_cap[sl];
             ik_lane = cc->inv_k[sl + 1];
-            if constexpr (!RESET) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+            if constexpr (!RESET && ACT == ACT_DICT) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+            if constexpr (!RESET && ACT == ACT_RAW) {
+                const float* v = resource + (env * n + sl) * (int64_t)(n + 1);
+                bool all_zero = true, have_nan = false;
+                float best = v[0];
+                int bi = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float x = v[j];
+                    all_zero = all_zero && (fabsf(x) <= 1e-8f);              // np.allclose(logits, 0), MRRL.PY:292
+                    if (!have_nan && (x != x)) { have_nan = true; bi = j; }   // np.argmax returns the first NaN
+                    if (!have_nan && x > best) { best = x; bi = j; }
+                }
+                tgt_in = all_zero ? 0 : bi % n;                               // MRRL.PY:293-295
+                double nrm = ((double)v[n] + 1.0) / 2.0;                      // MRRL.PY:297-299
+                nrm = nrm < 0.0 ? 0.0 : (nrm > 1.0 ? 1.0 : nrm);
+                res_in = (float)(0.1 + 0.9 * nrm);
+            }
         }
         uint4* ldst = reinterpret_cast<uint4*>(wbase);
         const int nvec = n_valid * p.rec_bytes / 16;
@@ -426,6 +450,19 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         __builtin_amdgcn_wave_barrier();
         STAMP(1);
 
+        if constexpr (!RESET && ACT == ACT_GREEDY) {
+            // target = argmin(nodes_load / cpu_caps), first minimum (np.argmin), the same for every acting agent
+            double ratio = agent ? qdiv(r_load[sl], cap_me, icap_me) : __builtin_inf();
+            int idx = sl;
+#pragma unroll
+            for (int m = LPE / 2; m > 0; m >>= 1) {
+                const double o = __shfl_xor(ratio, m);
+                const int oi = __shfl_xor(idx, m);
+                if (o < ratio || (o == ratio && oi < idx)) { ratio = o; idx = oi; }
+            }
+            tgt_in = agent ? idx : -1;
+            res_in = p.greedy_share;
+        }
         if constexpr (!RESET) {
             t_now = r_scal[S_TIME];
             // ---- placement phase: per-agent quantities in parallel on the lanes (MRRL.PY:397-423) ----
@@ -874,12 +911,13 @@ EnvParams make_params(const em_handle* h, int lanes)
     return p;
 }
 
-template <bool TAPE, bool RESET>
+template <bool TAPE, bool RESET, int ACT = ACT_DICT>
 int launch_env(em_handle* h, const int32_t* placement, const float* resource, const em_tape* tape,
-               const em_step_out* out, hipStream_t s)
+               const em_step_out* out, hipStream_t s, float greedy_share = 0.5f)
 {
     const int lanes = h->lanes;
-    const EnvParams p = make_params(h, lanes);
+    EnvParams p = make_params(h, lanes);
+    p.greedy_share = greedy_share;
     const int epw = 64 / lanes;
     const int n_work = h->wg_waves - 1;
     const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
@@ -891,13 +929,13 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     if (tape) tp = *tape;
     const dim3 grid((unsigned)blocks), block(64 * h->wg_waves);
 #define EM_LAUNCH(L)                                                                                              \
-    hipLaunchKernelGGL((env_kernel<L, TAPE, RESET>), grid, block, lds, s, p, h->d_state, h->d_const, placement,     \
+    hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT>), grid, block, lds, s, p, h->d_state, h->d_const, placement, \
                        resource, tp, *out, h->d_lat_log, h->d_err)
     if (lds > 64 * 1024) {
         hipError_t e = hipSuccess;
-        if (lanes == 16) e = hipFuncSetAttribute((const void*)env_kernel<16, TAPE, RESET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else if (lanes == 32) e = hipFuncSetAttribute((const void*)env_kernel<32, TAPE, RESET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else e = hipFuncSetAttribute((const void*)env_kernel<64, TAPE, RESET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lanes == 16) e = hipFuncSetAttribute((const void*)env_kernel<16, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (lanes == 32) e = hipFuncSetAttribute((const void*)env_kernel<32, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else e = hipFuncSetAttribute((const void*)env_kernel<64, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");
     }
     if (lanes == 16) EM_LAUNCH(16);
@@ -930,6 +968,27 @@ int check_tape(const em_handle* h, const em_tape* t, bool reset)
     return EM_OK;
 }
 
+}  // namespace
+
+namespace {
+template <int ACT>
+int step_with_policy(em_handle* h, const float* raw, float share, const em_tape* tape, const em_step_out* out, void* stream,
+                     const char* what)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "%s: null handle", what);
+    if (!h->was_reset) return em::fail(EM_ERR_STATE, "%s before em_reset", what);
+    int rc = check_out(h, out, true);
+    if (rc) return rc;
+    rc = check_tape(h, tape, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = tape ? launch_env<true, false, ACT>(h, nullptr, raw, tape, out, s, share)
+              : launch_env<false, false, ACT>(h, nullptr, raw, nullptr, out, s, share);
+    if (rc) return rc;
+    h->step += 1;
+    if (!h->explore_off) h->explore_counter += 1;   // MRRL.PY:467-468
+    return EM_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1028,6 +1087,19 @@ int em_step(em_handle* h, const int32_t* placement, const float* resource, const
     h->step += 1;
     if (!h->explore_off) h->explore_counter += 1;   // MRRL.PY:467-468
     return EM_OK;
+}
+
+int em_step_raw(em_handle* h, const float* raw_actions, const em_tape* tape, const em_step_out* out, void* stream)
+{
+    if (!raw_actions) return em::fail(EM_ERR_INVALID, "em_step_raw: raw_actions is required");
+    return step_with_policy<ACT_RAW>(h, raw_actions, 0.5f, tape, out, stream, "em_step_raw");
+}
+
+int em_step_greedy(em_handle* h, float resource_share, const em_tape* tape, const em_step_out* out, void* stream)
+{
+    if (!(resource_share > 0.0f) || !(resource_share <= 1.0f))
+        return em::fail(EM_ERR_INVALID, "em_step_greedy: resource_share must be in (0, 1]");
+    return step_with_policy<ACT_GREEDY>(h, nullptr, resource_share, tape, out, stream, "em_step_greedy");
 }
 
 int em_episode_metrics(em_handle* h, double* out6, void* stream)

@@ -182,6 +182,32 @@ class BatchedEdgeSimGym:
         info = {"reward_raw": self.reward_raw, "emitted": self.emitted, "rank": self.rank, "active": self.active}
         return self.obs, self.reward, self.done, self.truncated, info
 
+    def _step_result(self):
+        info = {"reward_raw": self.reward_raw, "emitted": self.emitted, "rank": self.rank, "active": self.active}
+        return self.obs, self.reward, self.done, self.truncated, info
+
+    def step_raw(self, raw: torch.Tensor, tape: DeviceTape | None = None):
+        """step() fed continuous action vectors ``raw[B, N, N+1]`` float32, converted on the device exactly as
+        ``EdgeSimGym._convert_action`` does (MRRL.PY:283-305)."""
+        B, n = self.n_envs, self.n_nodes
+        if raw.dtype != torch.float32 or tuple(raw.shape) != (B, n, n + 1) or not raw.is_contiguous():
+            raise ValueError(f"raw actions must be a contiguous float32 tensor of shape [{B}, {n}, {n + 1}]")
+        if raw.device != self.device:
+            raise ValueError("actions must live on the environment's device")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_step_raw(self._h, raw.data_ptr(), C.byref(tape.struct) if tape is not None else None,
+                                           C.byref(self._out), _stream_ptr(self.device)), "em_step_raw")
+        return self._step_result()
+
+    def step_greedy(self, resource_share: float = 0.5, tape: DeviceTape | None = None):
+        """step() under the greedy baseline's policy (MRRL.PY:803-812): argmin(load/capacity), fixed share;
+        the argmin is a wavefront-shuffle reduction inside the step kernel."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_step_greedy(self._h, float(resource_share),
+                                              C.byref(tape.struct) if tape is not None else None, C.byref(self._out),
+                                              _stream_ptr(self.device)), "em_step_greedy")
+        return self._step_result()
+
     def episode_metrics(self) -> torch.Tensor:
         out = torch.zeros((self.n_envs, 6), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):

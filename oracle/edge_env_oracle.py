@@ -537,6 +537,27 @@ class EdgeEnvOracle:
         }
 
 
+def convert_action(action, n):
+    """``EdgeSimGym._convert_action`` for a continuous vector (MRRL.PY:283-305): (placement, float32 resource)."""
+    vec = np.asarray(action, dtype=np.float32)
+    if vec.ndim == 0:
+        vec = vec.reshape(1)
+    if vec.size < n + 1:
+        padded = np.zeros(n + 1, dtype=np.float32)
+        padded[:vec.size] = vec
+        vec = padded
+    logits = vec[:-1]
+    placement = 0 if np.allclose(logits, 0) else int(np.argmax(logits)) % n
+    norm = (float(vec[-1]) + 1.0) / 2.0
+    value = 0.1 + 0.9 * np.clip(norm, 0.0, 1.0)
+    return placement, np.array([value], dtype=np.float32)[0]
+
+
+def greedy_action(load, cap):
+    """The greedy baseline's action (MRRL.PY:806-812): (argmin(load/cap), float32(0.5))."""
+    return int(np.argmin(np.asarray(load, np.float64) / np.asarray(cap, np.float64))), np.float32(0.5)
+
+
 class DictEnvOracle:
     """Adapter with the reference's ``reset()/step(action_dict)`` dict API (MRRL.PY:188,386)."""
 

@@ -70,15 +70,40 @@ def run_scenario(name, seed, cfg_over, action_mode, explore_counter0=0):
                 obs_all[i, a] = v
                 rank_all[i, a] = r
 
+        raws = np.zeros((T, n, n + 1), np.float32)
         od, _ = env.reset(seed=seed)
         put(0, od)
         load[0], queue[0], sim_time[0] = env.nodes_load, env.nodes_queue_len, env.sim_time
         metrics = None
         for t in range(T):
-            pl, rsrc = policy_actions(act_rs, n, action_mode)
+            if action_mode == "raw":
+                # continuous action vectors go through the reference's own _convert_action (MRRL.PY:276-305)
+                raw = act_rs.normal(0.0, 1.2, size=(n, n + 1)).astype(np.float32)
+                for a in range(n):
+                    c = act_rs.randint(0, 12)
+                    if c == 0:
+                        raw[a, :n] = 0.0                       # allclose(logits, 0) -> placement 0
+                    elif c == 1:
+                        raw[a, :n] = act_rs.uniform(-9e-9, 9e-9, size=n).astype(np.float32)
+                    elif c == 2:
+                        raw[a, act_rs.randint(0, n)] = raw[a, :n].max()   # tie: first maximum wins
+                    elif c == 3:
+                        raw[a, n] = np.float32(act_rs.choice([-1.0, 1.0, -3.5, 2.25, 0.0]))
+                raws[t] = raw
+                actions = {k: raw[int(k.split("_")[1])].copy() for k in od}
+                conv = [env._convert_action(raw[a]) for a in range(n)]
+                pl = np.array([c["placement"] for c in conv], np.int32)
+                rsrc = np.array([c["resource"][0] for c in conv], np.float32)
+            elif action_mode == "greedy":
+                # the reference's greedy baseline policy, verbatim in behaviour (MRRL.PY:803-812)
+                target = int(np.argmin(env.nodes_load / env.cpu_caps))
+                pl, rsrc = np.full(n, target, np.int32), np.full(n, 0.5, np.float32)
+                actions = {k: {"placement": target, "resource": np.array([0.5], dtype=np.float32)} for k in od}
+            else:
+                pl, rsrc = policy_actions(act_rs, n, action_mode)
+                actions = {k: {"placement": int(pl[int(k.split("_")[1])]),
+                               "resource": np.array([rsrc[int(k.split("_")[1])]], dtype=np.float32)} for k in od}
             placements[t], resources[t] = pl, rsrc
-            actions = {k: {"placement": int(pl[int(k.split("_")[1])]),
-                           "resource": np.array([rsrc[int(k.split("_")[1])]], dtype=np.float32)} for k in od}
             n_before = len(env.episode_latencies)
             viol_before = env.episode_violations
             od, rew, dn, _, infos = env.step(actions)
@@ -137,7 +162,7 @@ def run_scenario(name, seed, cfg_over, action_mode, explore_counter0=0):
         decay_steps=cfg["exploration_schedule"]["decay_steps"],
         arrival_mode=cfg["task_arrival_mode"],
         rate_range=np.array(cfg["task_arrival_rate_range"], np.float64),
-        placements=placements, resources=resources,
+        placements=placements, resources=resources, raws=raws, action_mode=action_mode,
         obs=obs_all, rank=rank_all, reward=reward, reward_emitted=emitted, done=done,
         load=load, queue=queue, sim_time=sim_time, step_lat=step_lat,
         n_viol=n_viol, n_tasks=n_tasks, n_completed=n_completed,
@@ -159,13 +184,17 @@ SCENARIOS = [
                                   "disable_env_exploration": True}, "random", 0),
     ("seed5_heavy_T120", 5, {"episode_length": 120, "task_arrival_rate_range": (30, 45),
                              "disable_env_exploration": True}, "random", 0),
+    ("seed6_rawvec_T150", 6, {"episode_length": 150, "disable_env_exploration": True}, "raw", 0),
+    ("seed7_greedy_T150", 7, {"episode_length": 150, "disable_env_exploration": True}, "greedy", 0),
 ]
 
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for sc in SCENARIOS:
-        run_scenario(*sc)
+        if not only or sc[0] in only:
+            run_scenario(*sc)
 
 
 
@@ -292,6 +321,8 @@ def run_mappo_scenario(name="mappo_seed0_T200", seed=0, T=200):
 
 
 if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--mappo" not in sys.argv:
         main()
-    run_mappo_scenario()
+    if not names:
+        run_mappo_scenario()

@@ -167,3 +167,23 @@ def test_gae_known_answer():
     # known answer obtained from the imported reference compute_gae
     adv, ret = c_oracle.gae([1, 2, 3], [0.5, 0.4, 0.3], [0, 0, 1], 0.0, 0.99, 0.95)
     assert list(adv) == [5.068387175000001, 4.436350000000001, 2.7]
+
+
+def test_convert_action_and_greedy_restatements_match_reference_fixtures():
+    """oracle.convert_action / greedy_action against what the reference's own _convert_action and greedy policy
+    produced when the fixtures were recorded (placements/resources are the reference's outputs)."""
+    import glob
+    import os
+    from tests.golden_util import GOLDEN, load_env_fixture
+    raw = load_env_fixture(os.path.join(GOLDEN, "env_seed6_rawvec_T150.npz"))
+    n = int(raw["n_nodes"])
+    assert str(raw["action_mode"]) == "raw"
+    for t in range(raw["raws"].shape[0]):
+        for a in range(n):
+            pl, rs = eo.convert_action(raw["raws"][t, a], n)
+            assert pl == raw["placements"][t, a] and rs == raw["resources"][t, a], (t, a)
+    gr = load_env_fixture(os.path.join(GOLDEN, "env_seed7_greedy_T150.npz"))
+    cap = np.asarray(eo.default_config()["node_cpu_capacity"], np.float64)
+    for t in range(gr["placements"].shape[0]):
+        pl, rs = eo.greedy_action(gr["load"][t], cap)
+        assert (gr["placements"][t] == pl).all() and (gr["resources"][t] == rs).all()
