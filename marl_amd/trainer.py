@@ -18,7 +18,7 @@ _STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tp
 
 class MAPPOTrainer:
     def __init__(self, env_config, seed=0, device="cuda:0", n_envs=1, rank=0, world_size=1, process_group=None,
-                 verbose=True):
+                 verbose=True, update_interval=1):
         if str(device) == "cuda":
             device = "cuda:0"
         self.device = torch.device(device)
@@ -46,8 +46,9 @@ class MAPPOTrainer:
         self.mappo = MAPPO(obs_dim=self.obs_dim, state_dim=self.state_dim, action_dim=self.action_dim,
                            n_agents=self.n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
                            value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4,
-                           device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
-                           process_group=process_group)
+                           device=self.device, n_envs=self.n_envs,
+                           horizon=self.env.episode_len * max(1, int(update_interval)), process_group=process_group)
+        self.update_interval = max(1, int(update_interval))   # episodes the rollout storage can hold before update()
         B, n = self.n_envs, self.n_agents
         self.placement = torch.zeros((B, n), dtype=torch.int32, device=self.device)
         self.resource = torch.full((B, n), 0.5, dtype=torch.float32, device=self.device)
@@ -74,25 +75,32 @@ class MAPPOTrainer:
             m.buffer = self._scratch_storage
         ro = m.buffer
         env.reset(tape=tapes[0] if tapes is not None else None)
-        m.begin_rollout()
+        # like the reference's list buffer, recorded episodes accumulate until update() clears them
+        # (mappo_trainer.py:281-282); the storage holds update_interval episodes
+        base = ro.steps_recorded if record_buffer else 0
+        if record_buffer and base + T > ro.horizon:
+            raise RuntimeError(f"rollout storage holds {ro.horizon // T} episode(s): call mappo.update() or construct "
+                               "MAPPOTrainer with a larger update_interval")
+        if base == 0:
+            m.begin_rollout()
         self.policy_episode += 1
         total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
         try:
             for t in range(T):
-                slot = t if record_buffer else 0
+                slot = base + t if record_buffer else 0
                 m.record_and_act(slot, env.obs, env.active, env.rank, self.placement, self.resource, explore=explore,
                                  noise=noise, seed=self.seed, episode=self.policy_episode, env_offset=self.env_offset,
                                  rng_step=t)
                 if record_buffer:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None,
-                             reward_seen_out=ro.t["reward_tb"][t], done_out=ro.t["done_tb"][t])
+                             reward_seen_out=ro.t["reward_tb"][slot], done_out=ro.t["done_tb"][slot])
                 else:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None)
                     total_reward += env.reward
         finally:
             m.buffer = self._train_storage
         if record_buffer:
-            total_reward = ro.t["reward_tb"].sum(dim=0)
+            total_reward = ro.t["reward_tb"][base:base + T].sum(dim=0)
         metrics = env.episode_metrics()                      # [B, 6] on the device
         # the reference harvests the metrics only when the final step produced observations
         # (mappo_trainer.py:222-231), otherwise it reports 0.0 for all of them
@@ -109,14 +117,16 @@ class MAPPOTrainer:
     def train(self, num_iterations=1000, update_interval=1, eval_interval=10, eval_episodes=10, max_total_steps=5_000_000):
         """mappo_trainer.py:252-316.  ``timestep`` counts environment steps of ONE environment (the reference's
         unit); the batch plays n_envs x world_size times as many."""
-        if update_interval != 1:
-            raise NotImplementedError("the device rollout storage holds one episode batch: update_interval must be 1")
+        if update_interval > self.update_interval:
+            raise ValueError(f"construct MAPPOTrainer(update_interval={update_interval}) so the device rollout storage "
+                             "can hold that many episodes")
         results_log, total_steps, iteration = [], 0, 0
         while True:
             iteration += 1
             episode_stats = self.train_episode(explore=True, record_buffer=True)
             total_steps += episode_stats["episode_steps"]
-            self.mappo.update()
+            if iteration % update_interval == 0:            # mappo_trainer.py:281-282
+                self.mappo.update()
             if iteration % eval_interval == 0:
                 eval_stats = self.evaluate(num_episodes=eval_episodes)
                 entry = {"algorithm": "MAPPO", "seed": self.seed, "iteration": iteration, "timestep": total_steps,

@@ -55,3 +55,10 @@ def test_product_does_not_import_oracle():
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert not re.search(r'#include\s*[<"][^>"]*oracle', src), f
                 assert "libedge_oracle" not in src and "dlopen" not in src, f
+
+
+def test_early_stop_threshold_matches_reference_example():
+    import run_mappo_batch as rb
+    # the reference's own worked example: baseline -1200, ratio 0.8 -> -1440 (run_mappo_batch.py:100-103)
+    assert rb._early_stop_threshold(-1200) == -1440.0
+    assert rb.EVAL_INTERVAL == 50_000 and rb.EVAL_EPISODES == 5 and rb.EARLY_STOP_WINDOW == 3

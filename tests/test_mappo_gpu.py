@@ -121,3 +121,48 @@ def test_batched_rollout_replicas_match_single():
     got = _params(tr.mappo)
     for k, v in want.items():
         np.testing.assert_allclose(got[k], v, rtol=2e-4, atol=4e-6, err_msg=k)
+
+
+def test_update_interval_two_accumulates_episodes_like_the_list_buffer():
+    """update_interval = 2 (mappo_trainer.py:281-282): two episodes per environment accumulate before update().
+    The reference runs ONE GAE over the flattened list of both episodes (mappo_algorithm.py:284-287) with the done flag
+    stored only on entries of a final step that has acting agents, so an episode whose last step is empty leaks into the
+    next one; the device scan over the dense [2T][B] rows must give exactly what the pinned gae_flat restatement gives
+    on each environment's flattened list."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.trainer import MAPPOTrainer
+    from oracle import mappo_oracle as mo
+    cfg = dict(ENV_CONFIG, episode_length=70)
+    B, T = 6, 70
+    tr = MAPPOTrainer(cfg, seed=3, device="cuda:0", n_envs=B, verbose=False, update_interval=2)
+    s1 = tr.train_episode(explore=True, record_buffer=True)
+    tr.evaluate(num_episodes=B)                       # an evaluation in between must not disturb the recorded batch
+    s2 = tr.train_episode(explore=True, record_buffer=True)
+    with pytest.raises(RuntimeError):
+        tr.train_episode(explore=True, record_buffer=True)     # storage full: the caller must update()
+    m, ro = tr.mappo, tr.mappo.buffer
+    E, S = ro.totals()
+    assert ro.steps_recorded == 2 * T and E > 0
+    m.compute_gae()
+    torch.cuda.synchronize()
+    t = {k: v.cpu().numpy() for k, v in ro.t.items()}
+    n_leaks = 0
+    for b in range(B):
+        rewards, values, dones, slots = [], [], [], []
+        for row in range(2 * T):
+            k, first = int(t["k_tb"][row, b]), int(t["first_tb"][row, b])
+            for j in range(k):
+                rewards.append(float(t["reward_tb"][row, b]))
+                values.append(float(t["value_tb"][row, b]))
+                dones.append(bool(t["done_tb"][row, b]))
+                slots.append(first + j)
+        if int(t["k_tb"][T - 1, b]) == 0:
+            n_leaks += 1                                  # first episode ends without a terminal flag on any entry
+        adv, ret = mo.gae_flat(rewards, values, dones)
+        assert np.array_equal(t["ent_adv"][slots], adv.astype(np.float32)), b
+        assert np.array_equal(t["ent_ret"][slots], ret.astype(np.float32)), b
+    assert s1["episode_steps"] == T and np.isfinite(s2["episode_reward"])
+    out = m.update()
+    assert ro.steps_recorded == 0 and np.isfinite(out["critic_loss"])
+    tr.train_episode(explore=True, record_buffer=True)     # storage is free again
+    print("episodes that leak into the next one:", n_leaks, "of", B)
