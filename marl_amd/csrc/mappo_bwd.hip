@@ -176,25 +176,54 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
 
     const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     const int64_t n_tiles = (a.n_rows + 15) >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row = tile * 16 + c;
-        const bool valid = row < a.n_rows;
-        const float* xr = a.x + (valid ? row : 0) * a.ldx;
-        float xb[KU * 4];
+    // x fragment of a tile: row c of the tile, features 16u + 4q + r
+    auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
+        const int64_t row_ = tile_ * 16 + c;
+        const bool valid_ = row_ < a.n_rows;
+        const float* xr = a.x + (valid_ ? row_ : 0) * a.ldx;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = 16 * u + 4 * q;
             if (vec_ok && k + 3 < K1) {
                 const float4 v = *reinterpret_cast<const float4*>(xr + k);
-                xb[u * 4 + 0] = v.x; xb[u * 4 + 1] = v.y; xb[u * 4 + 2] = v.z; xb[u * 4 + 3] = v.w;
+                xb_[u * 4 + 0] = v.x; xb_[u * 4 + 1] = v.y; xb_[u * 4 + 2] = v.z; xb_[u * 4 + 3] = v.w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xb[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+                for (int r = 0; r < 4; ++r) xb_[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
             }
         }
-        if (!valid) {
+        if (!valid_) {
 #pragma unroll
-            for (int s = 0; s < KU * 4; ++s) xb[s] = 0.0f;
+            for (int s = 0; s < KU * 4; ++s) xb_[s] = 0.0f;
+        }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    // narrow inputs leave registers for a software pipeline: the next tile's fragment is fetched while this tile
+    // computes.  The 140-wide critic already fills the register file (its prefetch spilled and ran 7 % slower).
+    constexpr bool PREFETCH = KU <= 4;
+    float xb[KU * 4];
+    if constexpr (PREFETCH) {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+        if (t0 < n_tiles) load_x(t0, xb);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
+        const int64_t row = tile * 16 + c;
+        const bool valid = row < a.n_rows;
+        if constexpr (!PREFETCH) load_x(tile, xb);
+        // loss inputs of this tile: issued now, needed after the forward pass
+        float p_act[4] = {0.f, 0.f, 0.f, 0.f}, p_adv = 0.0f, p_old = 0.0f;
+        int p_k = 0;
+        int64_t p_first = 0;
+        if constexpr (ACTOR) {
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < O) p_act[r] = a.action[row * O + 4 * q + r];
+                p_adv = a.adv[row];
+                p_old = a.old_logp[row];
+            }
+        } else {
+            if (valid && q == 0) { p_k = a.st_k[row]; p_first = a.st_first[row]; }
         }
         // ---- forward (recompute) -------------------------------------------------------------------
         f32x4 h1[4], h2[4], y;
@@ -211,6 +240,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
+        // the x fragment is dead from here on: fetch the next tile's into the same registers (the rest of this
+        // iteration hides the HBM latency; one wavefront per SIMD has nobody else to hide it)
+        if constexpr (PREFETCH) {
+            if (tile + tile_stride < n_tiles) load_x(tile + tile_stride, xb);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
 #pragma unroll
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
                 const int o = 4 * q + r;
                 d[r] = 0.0f;
                 if (o < O && valid) {
-                    d[r] = a.action[row * O + o] - y[r];
+                    d[r] = p_act[r] - y[r];
                     lp += -(d[r] * d[r]) / (2.0f * (sd[r] * sd[r])) - ls[r] - 0.91893853320467274f;
                 }
             }
@@ -248,8 +282,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
             lp += __shfl_xor(lp, 32);
             float g_lp = 0.0f;
             if (valid) {
-                const float A = (a.adv[row] - adv_mean) / adv_den;          // mappo_algorithm.py:293
-                const float ratio = expf(lp - a.old_logp[row]);             // :306
+                const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
+                const float ratio = expf(lp - p_old);                       // :306
                 const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
                 const float rc = fminf(fmaxf(ratio, lo), hi);
                 const float su1 = ratio * A, su2 = rc * A;                  // :307-308
@@ -276,8 +310,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         } else {
             if (valid && q == 0) {
                 const float v = y[0];
-                const int k = a.st_k[row];
-                const int64_t first = a.st_first[row];
+                const int k = p_k;
+                const int64_t first = p_first;
                 float gsum = 0.0f;
                 for (int j = 0; j < k; ++j) {
                     const float e = (v - a.norm_mean) / a.norm_scale - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;

@@ -278,9 +278,9 @@ class MAPPO:
                                       _stream(self.device)), "em_gae")
 
     # -- update (mappo_algorithm.py:264-345) -----------------------------------------------------------
-    def _waves(self, rows):
+    def _waves(self, rows, per_cu=1):
         tiles = (rows + 15) // 16
-        blocks = max(1, min(256, (tiles + 3) // 4))
+        blocks = max(1, min(256 * per_cu, (tiles + 3) // 4))
         return 4 * blocks
 
     def update(self):
