@@ -285,3 +285,49 @@ def test_greedy_baseline_rows_match_c_restatement():
     for k, i in (("avg_latency_ms", 0), ("p99_latency_ms", 1), ("avg_energy_J", 2), ("throughput_tps", 4), ("load_balance_jain", 5)):
         np.testing.assert_allclose(res[f"{k}_mean"], m[keep, i].mean(), rtol=1e-12)
         np.testing.assert_allclose(res[f"{k}_std"], m[keep, i].std(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,rates,B", [(3, (5, 15), 70), (8, (400, 700), 33), (16, (5, 15), 70), (17, (400, 700), 21),
+                                       (40, (5, 15), 9), (64, (500, 800), 5)])
+def test_other_topologies_and_heavy_arrivals_match_c_restatement(n, rates, B):
+    """Node counts that use the 16-, 32- and 64-lane packings, ragged batch sizes (partial wavefronts and partial
+    workgroups), and arrival rates high enough that a step brings more than the 8 arrivals drawn in parallel (the
+    sequential tail) - all bit-exact against the C restatement on the Philox stream, exploration on."""
+    from marl_amd.env import BatchedEdgeSimGym
+    T = 40
+    cfg = eo.default_config()
+    cfg.update(n_nodes=n, episode_length=T, task_arrival_rate_range=rates,
+               node_cpu_capacity=[(1.0 + 2.0 * i / max(1, n - 1)) * 1e9 for i in range(n)])
+    cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 30}
+    seed = 77 + n
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=seed, latency_log_capacity=T * n)
+    env.enable_debug_outputs()
+    ref = c_oracle.COracleEnv(cfg, B, seed=seed)
+    ref.set_explore(False, 0)
+    ref.next_episode()
+    r_obs, r_mask, _ = ref.reset()
+    obs, active = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), r_obs)
+    assert np.array_equal(active.cpu().numpy().astype(np.uint64), r_mask)
+    rs = np.random.RandomState(n)
+    max_arrivals = 0
+    for t in range(T):
+        pl = rs.randint(-1 if t % 7 == 0 else 0, n, size=(B, n)).astype(np.int32)
+        rsrc = rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32)
+        r_obs, r_rew, r_em, r_done = ref.step(pl, rsrc)
+        obs, rew, done, _, info = env.step(torch.as_tensor(pl).to(env.device), torch.as_tensor(rsrc).to(env.device))
+        assert np.array_equal(obs.cpu().numpy(), r_obs), t
+        assert np.array_equal(info["reward_raw"].cpu().numpy(), r_rew), t
+        assert np.array_equal(info["emitted"].cpu().numpy(), r_em) and np.array_equal(done.cpu().numpy(), r_done)
+        assert np.array_equal(env.rank.cpu().numpy(), ref.rank), t
+        assert np.array_equal(env.n_draws.cpu().numpy(), ref.n_draws), t
+        assert np.array_equal(env.step_latency.cpu().numpy(), ref.step_lat, equal_nan=True), t
+        max_arrivals = max(max_arrivals, (int(ref.n_draws.max()) - 3 - 5 * n) // 4)   # lower bound: <= 5 draws/agent + 3 + 4/arrival
+    st, rst = env.get_state(), ref.state()
+    for k in ("load", "queue", "sim_time", "elapsed", "step", "counts"):
+        assert np.array_equal(st[k], rst[k]), k
+    m, rm = env.episode_metrics().cpu().numpy(), ref.metrics()
+    assert np.array_equal(m[:, [1, 3, 4]], rm[:, [1, 3, 4]])
+    np.testing.assert_allclose(m, rm, rtol=1e-12, atol=0)
+    if rates[0] >= 400 and n <= 17:
+        assert max_arrivals > 8, "configuration failed to reach the sequential arrival tail"
