@@ -153,34 +153,16 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mappo", action="store_true", help="skip the full-loop MAPPO measurement")
-    ap.add_argument("--mappo-envs", type=int, default=65536, help="environments per GPU of the MAPPO measurement")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
-
+def time_env_steps(device, rank, world, B, steps, warmup):
+    """Times `steps` launches of em_step over B environments per GPU (configs[1] protocol): warmup, barrier +
+    synchronize, HIP events on the launch stream around the timed region, barrier + synchronize, MAX over ranks.
+    Returns (wall seconds, device milliseconds between the events, n_nodes, episode length, record bytes)."""
+    import torch.distributed as dist
     from marl_amd.config import ENV_CONFIG
     from marl_amd.env import BatchedEdgeSimGym
 
     cfg = dict(ENV_CONFIG)
     cfg["disable_env_exploration"] = True          # SURVEY.md 8d, config 2
-    B = args.envs
     env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B, latency_log_capacity=0)
     n = env.n_nodes
     T = env.episode_len
@@ -205,7 +187,7 @@ def main():
             counter[0] += 1
 
     counter = [0]
-    run(args.warmup, counter)
+    run(warmup, counter)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -213,7 +195,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    run(args.steps, counter)
+    run(steps, counter)
     ev1.record(stream)
     torch.cuda.synchronize(device)
     if world > 1:
@@ -225,11 +207,55 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    # parity spot check outside the timed region: done flags and a finite reward
+    # parity spot check outside the timed region: a finite reward
     assert bool(torch.isfinite(env.reward).all())
-    record_bytes, wg_waves = env.record_bytes, 8
+    record_bytes = env.record_bytes
     env.close()
+    del pool
+    return elapsed, dev_ms, n, T, record_bytes
+
+
+def traffic_for(B):
+    """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)).get(str(B))
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mappo", action="store_true", help="skip the full-loop MAPPO measurement")
+    ap.add_argument("--no-scale-point", action="store_true", help="skip the extra 65,536-environment measurement")
+    ap.add_argument("--mappo-envs", type=int, default=65536, help="environments per GPU of the MAPPO measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    B = args.envs
+    elapsed, dev_ms, n, T, record_bytes = time_env_steps(device, rank, world, B, args.steps, args.warmup)
+    wg_waves = 8
+    scale = None
+    if not args.no_scale_point and B != 65536:
+        # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)
+        k = max(200, args.steps // 4)
+        e2, d2, _, _, _ = time_env_steps(device, rank, world, 65536, k, max(20, args.warmup // 4))
+        scale = (65536, k, e2, d2)
     mappo = None
     if not args.no_mappo:
         mappo = mappo_leg(device, rank, world, args.mappo_envs)
@@ -239,13 +265,7 @@ def main():
         bytes_launch = algorithmic_bytes_per_env_step(n, record_bytes) * B
         launch_s = dev_ms * 1e-3 / args.steps          # HIP events on the launch stream, reset launches included
         achieved = bytes_launch / launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(str(B))
-            except Exception:
-                traffic = None
+        traffic = traffic_for(B)
         line = {
             "metric": "agent-steps/sec (env step)",
             "value": agent_steps / elapsed,
@@ -269,6 +289,15 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+        if scale is not None:
+            sb, sk, se, sd = scale
+            s_bytes = algorithmic_bytes_per_env_step(n, record_bytes) * sb
+            s_ach = s_bytes / (sd * 1e-3 / sk) / 1e9
+            line["scale_point"] = {"n_envs_per_gpu": sb, "steps": sk, "value": world * sb * n * sk / se,
+                                   "unit": "agent-steps/s", "avg_launch_us": sd * 1e3 / sk,
+                                   "roofline": {"bound": "hbm", "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": s_ach / HBM_PEAK_GBS, "traffic": traffic_for(sb),
+                                                "bytes_per_launch": s_bytes}}
         if mappo is not None:
             line["mappo"] = mappo
         print(json.dumps(line), flush=True)
