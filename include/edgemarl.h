@@ -134,7 +134,9 @@ int em_get_state(em_handle *h, double *load, double *queue, double *sim_time, do
 /* Bytes of one environment's state record and of one obs row block (for roofline accounting). */
 int64_t em_record_bytes(const em_handle *h);
 int64_t em_n_envs(const em_handle *h);
-/* Kernel variant: lanes per environment (16/32/64); 0 restores the automatic choice. */
+/* Kernel variant: lanes per environment - 16/32/64 (power-of-two groups) or 1 = packed (groups of exactly
+ * n_nodes lanes: more environments per wavefront); 0 restores the automatic choice (packed for batches of
+ * 65,536 environments or more when it fits more environments per wavefront).  Results do not depend on it. */
 int em_set_lanes_per_env(em_handle *h, int lanes);
 /* Kernel variant: wavefronts per workgroup of the reset/step kernel (waves - 1 worker wavefronts and one
  * scalar wavefront, 2..8); 0 restores the default.  Results do not depend on it. */

@@ -194,15 +194,17 @@ __device__ inline double np_sum_small(const double* a, int n)
 // record has even arrived (lanes 0..7: P_TASK_A, lanes 8..15: P_TASK_B); later arrivals (rare) are drawn
 // inline.  The stream is counter addressed, so this is bit-identical to drawing them one after the other
 // (oracle/edge_oracle.c does that).
-enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512 };
+enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512, EM_LANES_PACKED = 1, EM_PACKED_MIN_ENVS = 65536 };
 #ifndef EM_ENV_MIN_WAVES
 #define EM_ENV_MIN_WAVES 6     // wavefronts per SIMD the register allocation aims for
 #endif
 
+// bits of a wavefront ballot that belong to group g of width gw (LPE == 0: the packed layout, gw = n_nodes < 64)
 template <int LPE>
-__device__ inline uint64_t group_bits(uint64_t ballot, int g)
+__device__ inline uint64_t group_bits(uint64_t ballot, int g, int gw)
 {
     if constexpr (LPE == 64) return ballot;
+    else if constexpr (LPE == 0) return (ballot >> (g * gw)) & ((1ull << gw) - 1ull);
     else return (ballot >> (g * LPE)) & ((1ull << LPE) - 1ull);
 }
 
@@ -229,7 +231,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
                                                   const em_step_out out, double* __restrict__ lat_log,
                                                   int32_t* __restrict__ err_flag)
 {
-    constexpr int EPW = 64 / LPE;   // environments per worker wavefront
+    // LPE = 16/32/64: power-of-two lane groups.  LPE = 0: PACKED groups of exactly n lanes (n = 10: six
+    // environments per wavefront instead of four); lanes beyond the last whole group idle.  Identical results.
+    const int GW = LPE ? LPE : p.n;      // lanes per environment
+    const int EPW = 64 / GW;             // environments per worker wavefront
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int n = p.n, w = n + 4;
@@ -242,11 +247,13 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
 
     // worker coordinates (meaningless on the scalar wavefront)
-    const int g = lane / LPE, sl = lane % LPE, gbase = g * LPE;
+    const int g_raw = lane / GW, sl = lane - g_raw * GW;
+    const bool spare = g_raw >= EPW;                 // packed layout only: lanes past the last whole group
+    const int g = spare ? 0 : g_raw, gbase = g * GW; // (they shadow group 0 and never pass a valid/agent guard)
     const int64_t env0 = env_b0 + (int64_t)wave * EPW;
     const int n_valid = (scalar_wave || env0 >= p.n_envs) ? 0 : (int)((p.n_envs - env0) < EPW ? (p.n_envs - env0) : EPW);
     const int64_t env = env0 + g;
-    const bool valid = g < n_valid;
+    const bool valid = !spare && g < n_valid;
     const bool agent = valid && sl < n;
     const uint32_t envid = p.env_offset + (uint32_t)env;
 
@@ -279,7 +286,9 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     // values that live across the barrier
     double reward = 0.0, t_now = 0.0, cap_me = 1.0, icap_me = 1.0;
     int draws_lane = 0;
-    // pre-drawn task of lane sl < PAR_TASKS (philox mode)
+    // arrivals drawn in parallel per step: 8 with 16+ lanes per environment, n/2 in the packed layout
+    const int par_philox = (LPE == 0) ? (GW / 2 < PAR_TASKS ? GW / 2 : PAR_TASKS) : PAR_TASKS;
+    // pre-drawn task of lane sl < par_philox (philox mode)
     double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
     int pre_dec = 0;
 
@@ -398,19 +407,20 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         double net_bw = 0.0, net_lat = 0.0, ex_u = 2.0, ex_res = 0.0;
         int ex_tgt = 0;
         if constexpr (!TAPE) {
-            if (sl < 2 * PAR_TASKS) {
-                // lanes 0..7: P_TASK_A of arrival sl (workload, data); lanes 8..15: P_TASK_B of arrival sl-8
-                const bool is_a = sl < PAR_TASKS;
+            if (sl < 2 * par_philox) {
+                // lanes 0..par-1: P_TASK_A of arrival sl (workload, data); lanes par..2par-1: P_TASK_B of arrival sl-par
+                const bool is_a = sl < par_philox;
                 const uint4 b = philox(envid, p.episode, step_no,
-                                       ((is_a ? P_TASK_A : P_TASK_B) << 24) | (uint32_t)(is_a ? sl : sl - PAR_TASKS),
+                                       ((is_a ? P_TASK_A : P_TASK_B) << 24) | (uint32_t)(is_a ? sl : sl - par_philox),
                                        p.seed_lo, p.seed_hi);
                 const double ra = (is_a ? cc->wl_lo : cc->ddl_lo) + (is_a ? cc->wl_span : cc->ddl_span) * u53(b.x, b.y);
                 const double rb = cc->data_lo + cc->data_span * u53(b.z, b.w);
                 const int rz = (int)__umulhi(b.z, (uint32_t)n);
                 pre_wl = ra;
                 pre_data = rb;
-                pre_offs = __shfl_xor(ra, PAR_TASKS);     // lane j < 8 takes the deadline offset and the decider
-                pre_dec = __shfl_xor(rz, PAR_TASKS);      // of arrival j from lane j + 8
+                const int partner = gbase + (is_a ? sl + par_philox : sl - par_philox);
+                pre_offs = __shfl(ra, partner);           // lane j < par takes the deadline offset and the decider
+                pre_dec = __shfl(rz, partner);            // of arrival j from lane j + par
             }
             if constexpr (!RESET) {
                 if (agent) {
@@ -454,11 +464,19 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             // target = argmin(nodes_load / cpu_caps), first minimum (np.argmin), the same for every acting agent
             double ratio = agent ? qdiv(r_load[sl], cap_me, icap_me) : __builtin_inf();
             int idx = sl;
+            if constexpr (LPE == 0) {
+                const double mine = ratio;
+                for (int i = 0; i < GW; ++i) {       // packed groups are not a power of two: linear scan by shuffles
+                    const double o = __shfl(mine, gbase + i);
+                    if (o < ratio || (o == ratio && i < idx)) { ratio = o; idx = i; }
+                }
+            } else {
 #pragma unroll
-            for (int m = LPE / 2; m > 0; m >>= 1) {
-                const double o = __shfl_xor(ratio, m);
-                const int oi = __shfl_xor(idx, m);
-                if (o < ratio || (o == ratio && oi < idx)) { ratio = o; idx = oi; }
+                for (int m = LPE / 2; m > 0; m >>= 1) {
+                    const double o = __shfl_xor(ratio, m);
+                    const int oi = __shfl_xor(idx, m);
+                    if (o < ratio || (o == ratio && oi < idx)) { ratio = o; idx = oi; }
+                }
             }
             tgt_in = agent ? idx : -1;
             res_in = p.greedy_share;
@@ -529,7 +547,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g));
+            const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g, GW));
 
             STAMP(3);
             // ---- reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466) ----------------
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         s_ratio[sl] = ratio_me;
     }
     // arrivals 0..PAR-1 in parallel, arrival j on lane j of the group
-    constexpr int PAR = TAPE ? 16 : PAR_TASKS;
+    const int PAR = TAPE ? (GW < 16 ? GW : 16) : par_philox;
     const bool has = valid && sl < PAR && sl < n_new;
     double a_wl = pre_wl, a_data = pre_data, a_offs = pre_offs;
     int a_dec = pre_dec;
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool is_new = has && s_first[a_dec] == sl;
-    const uint32_t new_bits = (uint32_t)group_bits<LPE>(__ballot(is_new), g);
+    const uint32_t new_bits = (uint32_t)group_bits<LPE>(__ballot(is_new), g, GW);
     const int first_me = agent ? s_first[sl] : 0x7fffffff;
     const int q_me = agent ? r_queue[sl] : 0;              // queue length BEFORE this call's bumps (MRRL.PY:311)
     const bool pend_me = first_me != 0x7fffffff;
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     if (pend_me) { s_obs[sl * w] = ratio_me; s_obs[sl * w + 1] = (float)q_me; }
     // the other servers' load ratios: every lane writes its own ratio into the rows of the pending agents
     {
-        uint64_t pm = group_bits<LPE>(__ballot(pend_me), g);
+        uint64_t pm = group_bits<LPE>(__ballot(pend_me), g, GW);
         while (__ballot(pm != 0ull) != 0ull) {
             if (pm != 0ull) {
                 const int r = __ffsll((unsigned long long)pm) - 1;
@@ -673,7 +691,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
                 }
                 if (fresh) {                                    // _get_obs, MRRL.PY:307-324
                     const double rem = deadline - t_now;
-                    for (int c = sl; c < w; c += LPE) {
+                    for (int c = sl; c < w; c += GW) {
                         float v;
                         if (c == 0) v = s_ratio[dec];
                         else if (c == 1) v = q_now;
@@ -703,10 +721,16 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
     }
     const int rank_out = agent ? (int)r_rank[sl] : -1;
-    const uint64_t act_bits = group_bits<LPE>(__ballot(rank_out >= 0), g);
+    const uint64_t act_bits = group_bits<LPE>(__ballot(rank_out >= 0), g, GW);
     if (out.n_draws) {
         int d = draws_lane;
-        for (int m = LPE / 2; m > 0; m >>= 1) d += __shfl_xor(d, m, LPE);
+        if constexpr (LPE == 0) {
+            const int mine = d;
+            d = 0;
+            for (int i = 0; i < GW; ++i) d += __shfl(mine, gbase + i);
+        } else {
+            for (int m = LPE / 2; m > 0; m >>= 1) d += __shfl_xor(d, m, LPE);
+        }
         // once per environment: rate (random mode), window (step only), arrival count, 4 per arrival
         const int draws_env = (p.rate_mode == 2 ? 1 : 0) + (RESET ? 0 : 1) + 1 + 4 * n_new;
         if (valid && sl == 0) out.n_draws[env] = d + draws_env;
@@ -848,7 +872,16 @@ struct em_handle {
 
 namespace {
 
-int pick_lanes(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+int pow2_lanes(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+
+// Automatic layout: packed groups of n lanes when that fits more environments into a wavefront and the batch is
+// large enough to be throughput bound; power-of-two groups (shuffle butterflies, 8 parallel arrivals) otherwise.
+int pick_lanes(int n, int64_t n_envs)
+{
+    const int p2 = pow2_lanes(n);
+    if (n < 64 && 64 / n > 64 / p2 && n_envs >= EM_PACKED_MIN_ENVS) return EM_LANES_PACKED;
+    return p2;
+}
 
 EnvConst make_const(const em_config& c)
 {
@@ -886,7 +919,7 @@ EnvParams make_params(const em_handle* h, int lanes)
     p.explore = h->explore_off ? 0 : 1;
     p.rec_bytes = rec_bytes(p.n);
     p.obs_floats = p.n * (p.n + 4);
-    const int epw = 64 / lanes;
+    const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
     int wb = epw * p.rec_bytes;
     wb += (epw * p.obs_floats * 4 + 15) & ~15;
     wb += 2 * epw * (p.n < 8 ? 8 : p.n) * 8;   // latencies, energies of the step
@@ -918,8 +951,9 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     const int lanes = h->lanes;
     EnvParams p = make_params(h, lanes);
     p.greedy_share = greedy_share;
-    const int epw = 64 / lanes;
-    const int n_work = h->wg_waves - 1;
+    const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
+    // the scalar wavefront serves one environment per lane: at most 64 environments per workgroup
+    const int n_work = (h->wg_waves - 1) * epw <= 64 ? h->wg_waves - 1 : (64 / epw > 0 ? 64 / epw : 1);
     const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
     const int64_t blocks = (h->n_envs + epb - 1) / epb;
     const size_t lds = (size_t)p.wave_bytes * n_work + 64 * 12;
@@ -927,18 +961,20 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     em_tape tp;
     std::memset(&tp, 0, sizeof tp);
     if (tape) tp = *tape;
-    const dim3 grid((unsigned)blocks), block(64 * h->wg_waves);
+    const dim3 grid((unsigned)blocks), block(64 * (n_work + 1));
 #define EM_LAUNCH(L)                                                                                              \
     hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT>), grid, block, lds, s, p, h->d_state, h->d_const, placement, \
                        resource, tp, *out, h->d_lat_log, h->d_err)
     if (lds > 64 * 1024) {
         hipError_t e = hipSuccess;
-        if (lanes == 16) e = hipFuncSetAttribute((const void*)env_kernel<16, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lanes == EM_LANES_PACKED) e = hipFuncSetAttribute((const void*)env_kernel<0, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (lanes == 16) e = hipFuncSetAttribute((const void*)env_kernel<16, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else if (lanes == 32) e = hipFuncSetAttribute((const void*)env_kernel<32, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else e = hipFuncSetAttribute((const void*)env_kernel<64, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");
     }
-    if (lanes == 16) EM_LAUNCH(16);
+    if (lanes == EM_LANES_PACKED) EM_LAUNCH(0);
+    else if (lanes == 16) EM_LAUNCH(16);
     else if (lanes == 32) EM_LAUNCH(32);
     else EM_LAUNCH(64);
 #undef EM_LAUNCH
@@ -1017,7 +1053,7 @@ int em_create(const em_config* cfg, int64_t n_envs, int device_id, uint64_t seed
     h->env_offset = env_offset;
     h->explore_off = cfg->disable_env_exploration;
     h->lat_cap = latency_log_capacity;
-    h->lanes = pick_lanes(cfg->n_nodes);
+    h->lanes = pick_lanes(cfg->n_nodes, n_envs);
     const size_t sbytes = (size_t)n_envs * rec_bytes(cfg->n_nodes);
     hipError_t e = hipMalloc(&h->d_state, sbytes);
     if (e == hipSuccess) e = hipMemset(h->d_state, 0, sbytes);
@@ -1133,9 +1169,14 @@ int64_t em_n_envs(const em_handle* h) { return h ? h->n_envs : -1; }
 int em_set_lanes_per_env(em_handle* h, int lanes)
 {
     if (!h) return em::fail(EM_ERR_INVALID, "null handle");
-    if (lanes == 0) { h->lanes = pick_lanes(h->cfg.n_nodes); return EM_OK; }
+    if (lanes == 0) { h->lanes = pick_lanes(h->cfg.n_nodes, h->n_envs); return EM_OK; }
+    if (lanes == EM_LANES_PACKED) {
+        if (h->cfg.n_nodes >= 64) return em::fail(EM_ERR_INVALID, "the packed layout needs n_nodes < 64");
+        h->lanes = lanes;
+        return EM_OK;
+    }
     if ((lanes != 16 && lanes != 32 && lanes != 64) || lanes < h->cfg.n_nodes)
-        return em::fail(EM_ERR_INVALID, "lanes per env must be 16, 32 or 64 and >= n_nodes");
+        return em::fail(EM_ERR_INVALID, "lanes per env must be 1 (packed), 16, 32 or 64 and >= n_nodes");
     h->lanes = lanes;
     return EM_OK;
 }

@@ -28,7 +28,7 @@ def _mask_from_rank(rank):
     return sum((1 << i) for i, r in enumerate(rank) if r >= 0)
 
 
-@pytest.mark.parametrize("lanes", [0, 32, 64])
+@pytest.mark.parametrize("lanes", [0, 1, 32, 64])
 @pytest.mark.parametrize("path", env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
 def test_tape_parity_with_reference_goldens(path, lanes):
     from marl_amd.env import BatchedEdgeSimGym
@@ -137,7 +137,7 @@ def test_lane_packings_agree_and_absent_actions():
     for pl, rsrc in acts:
         o, r, e, d = ref.step(pl, rsrc)
         ref_trace.append((o.copy(), r.copy()))
-    for lanes, waves in ((16, 8), (32, 8), (64, 8), (16, 2), (16, 5), (32, 3)):
+    for lanes, waves in ((16, 8), (32, 8), (64, 8), (16, 2), (16, 5), (32, 3), (1, 8), (1, 2), (1, 4)):
         env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=5)
         env.set_lanes_per_env(lanes)
         env.set_workgroup_waves(waves)
@@ -230,7 +230,8 @@ def test_device_side_action_policies_match_reference(mode):
     np.testing.assert_allclose(m[0], g["metrics"], rtol=1e-12, atol=0)
 
 
-def test_greedy_argmin_with_nonzero_loads():
+@pytest.mark.parametrize("packed", [False, True])
+def test_greedy_argmin_with_nonzero_loads(packed):
     """The reference's unit quirk zeroes every load each step, so the recorded greedy target is always 0; a
     configuration with capacities in giga-cycles keeps loads alive and exercises the shuffle argmin against the
     C restatement driven by the host-side restatement of the policy."""
@@ -240,6 +241,7 @@ def test_greedy_argmin_with_nonzero_loads():
     cfg["node_cpu_capacity"] = [c / 1e9 * 3.0 for c in cfg["node_cpu_capacity"]]   # cycles/s ~ O(1): loads decay slowly
     B, n, seed = 67, 10, 31
     env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=seed)
+    env.set_lanes_per_env(1 if packed else 0)
     ref = c_oracle.COracleEnv(cfg, B, seed=seed)
     ref.set_explore(True, 0)
     ref.next_episode()
@@ -287,9 +289,10 @@ def test_greedy_baseline_rows_match_c_restatement():
         np.testing.assert_allclose(res[f"{k}_std"], m[keep, i].std(), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("n,rates,B", [(3, (5, 15), 70), (8, (400, 700), 33), (16, (5, 15), 70), (17, (400, 700), 21),
-                                       (40, (5, 15), 9), (64, (500, 800), 5)])
-def test_other_topologies_and_heavy_arrivals_match_c_restatement(n, rates, B):
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("n,rates,B", [(1, (5, 15), 130), (2, (400, 700), 75), (3, (5, 15), 70), (8, (400, 700), 33),
+                                       (16, (5, 15), 70), (17, (400, 700), 21), (40, (5, 15), 9), (64, (500, 800), 5)])
+def test_other_topologies_and_heavy_arrivals_match_c_restatement(n, rates, B, packed):
     """Node counts that use the 16-, 32- and 64-lane packings, ragged batch sizes (partial wavefronts and partial
     workgroups), and arrival rates high enough that a step brings more than the 8 arrivals drawn in parallel (the
     sequential tail) - all bit-exact against the C restatement on the Philox stream, exploration on."""
@@ -300,7 +303,11 @@ def test_other_topologies_and_heavy_arrivals_match_c_restatement(n, rates, B):
                node_cpu_capacity=[(1.0 + 2.0 * i / max(1, n - 1)) * 1e9 for i in range(n)])
     cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 30}
     seed = 77 + n
+    if packed and n >= 64:
+        pytest.skip("64 nodes fill the wavefront: nothing to pack")
     env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=seed, latency_log_capacity=T * n)
+    if packed:
+        env.set_lanes_per_env(1)     # groups of exactly n lanes (the layout large batches use by default)
     env.enable_debug_outputs()
     ref = c_oracle.COracleEnv(cfg, B, seed=seed)
     ref.set_explore(False, 0)

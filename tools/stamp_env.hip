@@ -23,6 +23,7 @@ int main(int argc, char** argv)
     c.initial_epsilon = 1.0; c.final_epsilon = 0.05; c.decay_steps = 1000000;
     em_handle* h = nullptr;
     if (em_create(&c, B, 0, 7, 0, 0, &h)) { printf("create: %s\n", em_last_error()); return 1; }
+    if (argc > 4 && em_set_lanes_per_env(h, atoi(argv[4]))) { printf("lanes: %s\n", em_last_error()); return 1; }
     if (argc > 3 && em_set_workgroup_waves(h, atoi(argv[3]))) { printf("waves: %s\n", em_last_error()); return 1; }
     const int n = 10;
     std::vector<int32_t> pl(B * n);
