@@ -61,6 +61,15 @@ class EdgeSimGym:
 
     def step(self, action_dict):
         n = self.n_nodes
+        env = self._env
+        if len(action_dict) == n and all(not isinstance(a, dict) and np.size(a) == n + 1 for a in action_dict.values()):
+            # every agent supplied a full continuous vector: converted on the device (em_step_raw)
+            raw = np.zeros((1, n, n + 1), np.float32)
+            for name, act in action_dict.items():
+                raw[0, int(name.split("_")[1])] = np.asarray(act, np.float32).reshape(-1)
+            env.global_step_counter = EdgeSimGym._global_step_counter
+            env.step_raw(torch.from_numpy(raw).to(env.device))
+            return self._after_step()
         pl = np.full((1, n), -1, np.int32)       # agents without an entry are not dispatched (MRRL.PY:397-399)
         rs = np.full((1, n), 0.5, np.float32)
         for name, act in action_dict.items():
@@ -76,9 +85,12 @@ class EdgeSimGym:
                 rs[0, a] = np.float32(0.1 + 0.9 * np.clip((float(vec[-1]) + 1.0) / 2.0, 0.0, 1.0))
         self._placement.copy_(torch.from_numpy(pl))
         self._resource.copy_(torch.from_numpy(rs))
-        env = self._env
         env.global_step_counter = EdgeSimGym._global_step_counter
         env.step(self._placement, self._resource)
+        return self._after_step()
+
+    def _after_step(self):
+        env = self._env
         EdgeSimGym._global_step_counter = env.global_step_counter
         self.current_step += 1
         obs = self._obs_dict()
