@@ -153,26 +153,33 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 
     const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
 
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row = tile * 16 + c;          // row relative to row_base
-        const bool valid = row < n_rows;
-        const float* xr = a.x + (row_base + (valid ? row : 0)) * a.ldx;
-        float xb[KU * 4];
+    // x fragment of a tile: row c of the tile, features 16u + 4q + r
+    auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
+        const int64_t row_ = tile_ * 16 + c;
+        const bool valid_ = row_ < n_rows;
+        const float* xr = a.x + (row_base + (valid_ ? row_ : 0)) * a.ldx;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = 16 * u + 4 * q;
             if (vec_ok && k + 3 < K1) {
                 const float4 v = *reinterpret_cast<const float4*>(xr + k);
-                xb[u * 4 + 0] = v.x; xb[u * 4 + 1] = v.y; xb[u * 4 + 2] = v.z; xb[u * 4 + 3] = v.w;
+                xb_[u * 4 + 0] = v.x; xb_[u * 4 + 1] = v.y; xb_[u * 4 + 2] = v.z; xb_[u * 4 + 3] = v.w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xb[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+                for (int r = 0; r < 4; ++r) xb_[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
             }
         }
-        if (!valid) {
+        if (!valid_) {
 #pragma unroll
-            for (int s = 0; s < KU * 4; ++s) xb[s] = 0.0f;
+            for (int s = 0; s < KU * 4; ++s) xb_[s] = 0.0f;
         }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    float xb[KU * 4];
+    load_x((int64_t)blockIdx.x * 4 + wave, xb);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
+        const int64_t row = tile * 16 + c;          // row relative to row_base
+        const bool valid = row < n_rows;
         f32x4 h1[4], h2[4], y;
 #pragma unroll
         for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
@@ -184,6 +191,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
+        // the x fragment is dead from here on: fetch the next tile's while this one finishes (one wavefront per SIMD)
+        if (tile + tile_stride < n_tiles) load_x(tile + tile_stride, xb);
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
 #pragma unroll
