@@ -115,6 +115,23 @@ int em_step_raw(em_handle *h, const float *raw_actions, const em_tape *tape, con
  * agent targets argmin(nodes_load / cpu_caps) (first minimum) with the given resource share (reference 0.5). */
 int em_step_greedy(em_handle *h, float resource_share, const em_tape *tape, const em_step_out *out, void *stream);
 
+/* k_steps consecutive EdgeSimGym.step calls (MRRL.PY:386-521) in ONE launch, for callers whose actions do not
+ * depend on the observations of the steps in between (pre-generated or scripted actions, the greedy baseline): the
+ * state records stay on chip between the steps, so a step costs neither a kernel launch nor a record round trip.
+ * Bit-identical to k_steps calls of em_step / em_step_raw / em_step_greedy on the in-kernel random stream (no tape).
+ * action_mode EM_ACTIONS_DICT: placement [k][n_envs][n] + resource [k][n_envs][n]; EM_ACTIONS_RAW: resource_or_raw =
+ * vectors [k][n_envs][n][n+1]; EM_ACTIONS_GREEDY: no arrays, greedy_share.  history bit EM_HISTORY_REWARDS: the
+ * reward / reward_seen / emitted / done outputs are [k][n_envs] arrays (one row per step), bit EM_HISTORY_OBS: the same for
+ * obs / active / rank; without a bit the output holds the last step only.  No counterpart in the reference (it steps
+ * one environment at a time from Python); callers: evaluation baselines and open-loop benchmarks. */
+#define EM_ACTIONS_DICT 0
+#define EM_ACTIONS_RAW 1
+#define EM_ACTIONS_GREEDY 2
+#define EM_HISTORY_REWARDS 1
+#define EM_HISTORY_OBS 2
+int em_step_many(em_handle *h, int32_t k_steps, int32_t action_mode, const int32_t *placement, const float *resource_or_raw,
+                 float greedy_share, int32_t history, const em_step_out *out, void *stream);
+
 /* Episode metrics (MRRL.PY:470-504), out6 = device [n_envs][6] float64:
  * avg_latency_ms, p99_latency_ms (NaN without a latency log), avg_energy_J, violation_rate,
  * throughput_tps, load_balance_jain. */

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
     L.em_step.argtypes = [vp, vp, vp, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
     L.em_step_raw.argtypes = [vp, vp, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
     L.em_step_greedy.argtypes = [vp, C.c_float, C.POINTER(EmTape), C.POINTER(EmStepOut), vp]
+    L.em_step_many.argtypes = [vp, i32, i32, vp, vp, C.c_float, i32, C.POINTER(EmStepOut), vp]
     L.em_episode_metrics.argtypes = [vp, vp, vp]
     L.em_set_exploration.argtypes = [vp, i32, i64]
     L.em_get_exploration_counter.argtypes = [vp]
@@ -101,7 +102,7 @@ def lib() -> C.CDLL:
                  "em_ppo_critic_grad", "em_adam_step"):
         getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
-                 "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves", "em_step_raw", "em_step_greedy"):
+                 "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves", "em_step_raw", "em_step_greedy", "em_step_many"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

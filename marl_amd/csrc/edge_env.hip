@@ -59,6 +59,10 @@ struct EnvParams {
     double eps;
     int32_t step_no;
     float greedy_share;          // resource share of the greedy policy (ACT_GREEDY)
+    int32_t k_steps, pad2;       // consecutive steps taken by this launch (em_step_many; 1 otherwise)
+    int64_t hist_stride;         // per-step stride (in environments) of reward/emitted/done outputs: 0 = overwrite
+    int64_t obs_hist_stride;     // same for obs/active/rank
+    int64_t explore_counter0;    // exploration step counter at the first step of the launch (MRRL.PY:122)
     // step_no: 1-based index of the step being taken (all environments of a handle move together)
     uint32_t seed_lo, seed_hi, episode, env_offset;
     int64_t n_envs, lat_cap;
@@ -73,6 +77,7 @@ struct EnvConst {
     double rate_lo, rate_span, rate_mid, cycle, inv_cycle;
     double wl_lo, wl_span, data_lo, data_span, ddl_lo, ddl_span, bw_lo, bw_span, lat_lo, lat_span;
     double w_lat, w_en, w_viol, dt_min, dt_max, window0;
+    double eps_init, eps_final, eps_span;    // exploration schedule (MRRL.PY:249-256)
     double cap[EM_MAX_NODES], inv_cap[EM_MAX_NODES], inv_k[EM_MAX_NODES + 1];
 };
 
@@ -242,9 +247,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     const int n_work = (int)(blockDim.x >> 6) - 1;
     const bool scalar_wave = wave == n_work;
     const int64_t env_b0 = (int64_t)blockIdx.x * (n_work * EPW);   // first environment of the workgroup
-    const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
-    double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [64] window per environment
-    int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
+    const uint32_t step_first = RESET ? 0u : (uint32_t)p.step_no;
+    const int K = RESET ? 1 : p.k_steps;            // consecutive steps of this launch; the records stay in LDS
+    double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [2][64] window per environment
+    int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 128);                 // [2][64] arrivals per environment
 
     // worker coordinates (meaningless on the scalar wavefront)
     const int g_raw = lane / GW, sl = lane - g_raw * GW;
@@ -283,25 +289,15 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     off += EPW * n * 4;
     int32_t* s_first = reinterpret_cast<int32_t*>(wbase + off) + g * n;   // first arrival index per decider
 
-    // values that live across the barrier
-    double reward = 0.0, t_now = 0.0, cap_me = 1.0, icap_me = 1.0;
-    int draws_lane = 0;
-    // arrivals drawn in parallel per step: 8 with 16+ lanes per environment, n/2 in the packed layout
-    const int par_philox = (LPE == 0) ? (GW / 2 < PAR_TASKS ? GW / 2 : PAR_TASKS) : PAR_TASKS;
-    // pre-drawn task of lane sl < par_philox (philox mode)
-    double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
-    int pre_dec = 0;
-
-    if (scalar_wave) {
-        // =========================== scalar wavefront: one environment per lane ===========================
-        STAMP(12);
-        const int64_t e = env_b0 + lane;
-        const bool v = lane < n_work * EPW && e < p.n_envs;
-        const uint32_t eid = p.env_offset + (uint32_t)e;
-        double t0 = 0.0;
-        if constexpr (!RESET) {
-            if (v) t0 = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
-        }
+    // =========================== scalar wavefront: one environment per lane ===========================
+    // It owns each environment's clock for the launch (t(k+1) = t(k) + window(k), the very sum the workers store),
+    // so with several steps per launch it runs one step ahead of the workers; results go to a two-deep LDS buffer.
+    const int64_t e = env_b0 + lane;
+    const bool v = scalar_wave && lane < n_work * EPW && e < p.n_envs;
+    const uint32_t eid = p.env_offset + (uint32_t)e;
+    double sc_t = 0.0;
+    auto scalar_step = [&](uint32_t step_no, int buf) {
+        const double t0 = sc_t;
         double rate_u = 0.0, dt_u = 0.0;
         double pu[PRE_POIS_U] = {0.0};     // first uniforms of the Knuth loop, drawn while the clock loads
         if constexpr (!TAPE) {
@@ -362,23 +358,56 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
                 }
             }
         }
-        s_win[lane] = window;
-        s_nnew[lane] = n_new;
+        s_win[buf * 64 + lane] = window;
+        s_nnew[buf * 64 + lane] = n_new;
+        sc_t = t0 + window;          // the clock of the next step (workers add the same window, MRRL.PY:444-447)
         STAMP(14);
-    } else {
+    };
+    if (scalar_wave) {
+        STAMP(12);
+        if constexpr (!RESET) {
+            if (v) sc_t = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
+        }
+        scalar_step(step_first, 0);
+    }
+
+    // worker values that persist over the launch
+    double cap_me = 1.0, icap_me = 1.0, ik_lane = 0.0;
+    // arrivals drawn in parallel per step: 8 with 16+ lanes per environment, n/2 in the packed layout
+    const int par_philox = (LPE == 0) ? (GW / 2 < PAR_TASKS ? GW / 2 : PAR_TASKS) : PAR_TASKS;
+
+    for (int ks = 0; ks < K; ++ks) {
+    const uint32_t step_no = step_first + (uint32_t)ks;
+    // values that live across the barrier
+    double reward = 0.0, t_now = 0.0;
+    int draws_lane = 0;
+    // pre-drawn task of lane sl < par_philox (philox mode)
+    double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
+    int pre_dec = 0;
+    // epsilon of this step, _get_current_epsilon (MRRL.PY:249-256)
+    double eps_k = 0.0;
+    if (p.explore) {
+        double frac = (double)(p.explore_counter0 + ks) / cc->eps_span;
+        if (frac > 1.0) frac = 1.0;
+        eps_k = cc->eps_init - (cc->eps_init - cc->eps_final) * frac;
+    }
+
+    if (!scalar_wave) {
         // =========================== worker wavefront, part 1: placements ================================
         STAMP(0);
         // global loads first: actions, capacity tables, the records
         int tgt_in = -1;
         float res_in = 1.0f;
-        double ik_lane = 0.0;
+        const int64_t aenv = env + (int64_t)ks * p.n_envs;      // row of this step in [k_steps][n_envs] action arrays
         if (agent) {
-            cap_me = cc->cap[sl];
-            icap_me = cc->inv_cap[sl];
-            ik_lane = cc->inv_k[sl + 1];
-            if constexpr (!RESET && ACT == ACT_DICT) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+            if (ks == 0) {
+                cap_me = cc->cap[sl];
+                icap_me = cc->inv_cap[sl];
+                ik_lane = cc->inv_k[sl + 1];
+            }
+            if constexpr (!RESET && ACT == ACT_DICT) { tgt_in = placement[aenv * n + sl]; res_in = resource[aenv * n + sl]; }
             if constexpr (!RESET && ACT == ACT_RAW) {
-                const float* v = resource + (env * n + sl) * (int64_t)(n + 1);
+                const float* v = resource + (aenv * n + sl) * (int64_t)(n + 1);
                 bool all_zero = true, have_nan = false;
                 float best = v[0];
                 int bi = 0;
@@ -398,9 +427,11 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         const int nvec = n_valid * p.rec_bytes / 16;
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
         if constexpr (!RESET) {
-            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
-            if (lane < nvec) v0 = src[lane];
-            if (lane + 64 < nvec) v1 = src[lane + 64];
+            if (ks == 0) {       // later steps of the launch find the records in LDS
+                const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+                if (lane < nvec) v0 = src[lane];
+                if (lane + 64 < nvec) v1 = src[lane + 64];
+            }
         }
 
         // random numbers that depend only on (environment, step, lane): evaluated while the loads fly
@@ -431,7 +462,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
                         const uint4 e1 = philox(envid, p.episode, step_no, (P_EXPL << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
                         ex_u = u53(e1.x, e1.y);
                         ex_tgt = (int)__umulhi(e1.z, (uint32_t)n);
-                        if (!(ex_u > p.eps)) {
+                        if (!(ex_u > eps_k)) {
                             const uint4 e2 = philox(envid, p.episode, step_no, (P_EXPL_RES << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
                             ex_res = 0.1 + (1.0 - 0.1) * u53(e2.x, e2.y);
                         }
@@ -441,14 +472,16 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
 
         // ---- stage in: records (zeros at reset), zeroed observation tile, per-step scratch -----------
-        const int nstage = RESET ? EPW * p.rec_bytes / 16 : nvec;
-        if (lane < nstage) ldst[lane] = v0;
-        if (lane + 64 < nstage) ldst[lane + 64] = v1;
-        if constexpr (RESET) {
-            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
-        } else {
-            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
-            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
+        if (ks == 0) {
+            const int nstage = RESET ? EPW * p.rec_bytes / 16 : nvec;
+            if (lane < nstage) ldst[lane] = v0;
+            if (lane + 64 < nstage) ldst[lane + 64] = v1;
+            if constexpr (RESET) {
+                for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
+            } else {
+                const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+                for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
+            }
         }
         {
             uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
@@ -502,7 +535,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             if (p.explore && acting) {   // _maybe_apply_env_exploration, MRRL.PY:258-274
                 if constexpr (TAPE) ex_u = tape.explore_u[env * n + slot];
                 draws_lane += 1;
-                if (!(ex_u > p.eps)) {
+                if (!(ex_u > eps_k)) {
                     if constexpr (TAPE) {
                         ex_tgt = tape.explore_tgt[env * n + slot];
                         ex_res = tape.explore_res[env * n + slot];
@@ -597,13 +630,16 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         STAMP(4);
     }
 
-    __syncthreads();   // the scalar wavefront's windows and arrival counts are in LDS
-    if (scalar_wave) return;
+    __syncthreads();   // the scalar wavefront's windows and arrival counts of this step are in LDS
+    if (scalar_wave) {
+        if (ks + 1 < K) scalar_step(step_no + 1u, (ks + 1) & 1);    // one step ahead of the workers
+        continue;
+    }
 
     // =============================== worker wavefront, part 2: arrivals (MRRL.PY:340-383) ===============
     STAMP(5);
-    const double window = s_win[wave * EPW + g];
-    const int n_new = valid ? s_nnew[wave * EPW + g] : 0;
+    const double window = s_win[(ks & 1) * 64 + wave * EPW + g];
+    const int n_new = valid ? s_nnew[(ks & 1) * 64 + wave * EPW + g] : 0;
     float ratio_me = 0.0f;
     if (agent) {
         r_rank[sl] = -1;
@@ -740,25 +776,28 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             r_scal[S_TIME] = t_now + window;               // delta_t > 0 always: dt_min > 0
             r_scal[S_ELAPSED] = r_scal[S_ELAPSED] + window;
             r_int[I_STEP] = (int32_t)step_no;
-            if (out.reward) out.reward[env] = reward;
-            if (out.emitted) out.emitted[env] = n_pending > 0;
-            if (out.reward_seen) out.reward_seen[env] = n_pending > 0 ? reward : 0.0;
-            if (out.done) out.done[env] = (int32_t)step_no >= p.horizon;
+            const int64_t he = env + (int64_t)ks * p.hist_stride;
+            if (out.reward) out.reward[he] = reward;
+            if (out.emitted) out.emitted[he] = n_pending > 0;
+            if (out.reward_seen) out.reward_seen[he] = n_pending > 0 ? reward : 0.0;
+            if (out.done) out.done[he] = (int32_t)step_no >= p.horizon;
         }
         r_int[I_PENDING] = n_pending;
-        out.active[env] = act_bits;
+        out.active[env + (int64_t)ks * p.obs_hist_stride] = act_bits;
     }
-    if (agent && out.rank) out.rank[env * n + sl] = (int8_t)rank_out;
+    if (agent && out.rank) out.rank[(env + (int64_t)ks * p.obs_hist_stride) * n + sl] = (int8_t)rank_out;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     STAMP(10);
     // ---- stage out: records and observation tile, 16-byte lane-linear stores -------------------------
-    {
+    if (ks == K - 1) {      // the records leave LDS once per launch
         const uint4* src = reinterpret_cast<const uint4*>(wbase);
         uint4* dst = reinterpret_cast<uint4*>(state + env0 * p.rec_bytes);
         for (int i = lane; i < n_valid * p.rec_bytes / 16; i += 64) dst[i] = src[i];
-        const int64_t fbase = env0 * p.obs_floats;
+    }
+    if (ks == K - 1 || p.obs_hist_stride != 0) {
+        const int64_t fbase = (env0 + (int64_t)ks * p.obs_hist_stride) * p.obs_floats;
         const int nfl = n_valid * p.obs_floats;
         float* gobs = out.obs + fbase;
         if ((fbase & 3) == 0) {
@@ -771,6 +810,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
     }
     STAMP(11);
+    }   // steps of the launch
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,6 +938,8 @@ EnvConst make_const(const em_config& c)
     k.lat_lo = c.net_latency_lo; k.lat_span = c.net_latency_hi - c.net_latency_lo;
     k.w_lat = c.w_latency; k.w_en = c.w_energy; k.w_viol = c.w_violation;
     k.dt_min = c.min_time_step; k.dt_max = c.max_time_step; k.window0 = c.initial_observation_window;
+    k.eps_init = c.initial_epsilon; k.eps_final = c.final_epsilon;
+    k.eps_span = (double)(c.decay_steps > 1 ? c.decay_steps : 1);
     for (int i = 0; i < EM_MAX_NODES; ++i) {
         const double cap = i < c.n_nodes ? c.node_cpu_capacity[i] : 1.0;
         k.cap[i] = cap;
@@ -926,15 +968,9 @@ EnvParams make_params(const em_handle* h, int lanes)
     wb += epw * 8;                 // acting-rank masks
     wb += 2 * epw * p.n * 4;       // load ratios, first arrival per decider
     p.wave_bytes = (wb + 15) & ~15;
-    // _get_current_epsilon, MRRL.PY:249-256
-    double eps = 0.0;
-    if (!h->explore_off) {
-        const int64_t span = c.decay_steps > 1 ? c.decay_steps : 1;
-        double frac = (double)h->explore_counter / (double)span;
-        if (frac > 1.0) frac = 1.0;
-        eps = c.initial_epsilon - (c.initial_epsilon - c.final_epsilon) * frac;
-    }
-    p.eps = eps;
+    p.eps = 0.0;                                   // epsilon is evaluated per step inside the kernel
+    p.explore_counter0 = h->explore_counter;
+    p.k_steps = 1;
     p.seed_lo = (uint32_t)h->seed; p.seed_hi = (uint32_t)(h->seed >> 32);
     p.episode = h->episode;
     p.step_no = h->step + 1;
@@ -946,17 +982,20 @@ EnvParams make_params(const em_handle* h, int lanes)
 
 template <bool TAPE, bool RESET, int ACT = ACT_DICT>
 int launch_env(em_handle* h, const int32_t* placement, const float* resource, const em_tape* tape,
-               const em_step_out* out, hipStream_t s, float greedy_share = 0.5f)
+               const em_step_out* out, hipStream_t s, float greedy_share = 0.5f, int k_steps = 1, int history = 0)
 {
     const int lanes = h->lanes;
     EnvParams p = make_params(h, lanes);
     p.greedy_share = greedy_share;
+    p.k_steps = k_steps;
+    p.hist_stride = (history & EM_HISTORY_REWARDS) ? h->n_envs : 0;
+    p.obs_hist_stride = (history & EM_HISTORY_OBS) ? h->n_envs : 0;
     const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
     // the scalar wavefront serves one environment per lane: at most 64 environments per workgroup
     const int n_work = (h->wg_waves - 1) * epw <= 64 ? h->wg_waves - 1 : (64 / epw > 0 ? 64 / epw : 1);
     const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
     const int64_t blocks = (h->n_envs + epb - 1) / epb;
-    const size_t lds = (size_t)p.wave_bytes * n_work + 64 * 12;
+    const size_t lds = (size_t)p.wave_bytes * n_work + 2 * 64 * 12;   // + two-deep window/arrival-count buffers
     if (lds > 160 * 1024) return em::fail(EM_ERR_INVALID, "n_nodes too large for the LDS tile (%zu bytes)", lds);
     em_tape tp;
     std::memset(&tp, 0, sizeof tp);
@@ -1122,6 +1161,40 @@ int em_step(em_handle* h, const int32_t* placement, const float* resource, const
     if (rc) return rc;
     h->step += 1;
     if (!h->explore_off) h->explore_counter += 1;   // MRRL.PY:467-468
+    return EM_OK;
+}
+
+int em_step_many(em_handle* h, int32_t k_steps, int32_t action_mode, const int32_t* placement, const float* resource_or_raw,
+                 float greedy_share, int32_t history, const em_step_out* out, void* stream)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "em_step_many: null handle");
+    if (!h->was_reset) return em::fail(EM_ERR_STATE, "em_step_many before em_reset");
+    if (k_steps < 1 || (int64_t)h->step + k_steps > h->cfg.episode_length)
+        return em::fail(EM_ERR_INVALID, "em_step_many: %d steps from step %d leave the episode of %d steps", k_steps, h->step,
+                        h->cfg.episode_length);
+    if (history & ~(EM_HISTORY_REWARDS | EM_HISTORY_OBS)) return em::fail(EM_ERR_INVALID, "em_step_many: unknown history bits");
+    int rc = check_out(h, out, true);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (action_mode) {
+    case EM_ACTIONS_DICT:
+        if (!placement || !resource_or_raw) return em::fail(EM_ERR_INVALID, "em_step_many: placement/resource are required");
+        rc = launch_env<false, false, ACT_DICT>(h, placement, resource_or_raw, nullptr, out, s, 0.5f, k_steps, history);
+        break;
+    case EM_ACTIONS_RAW:
+        if (!resource_or_raw) return em::fail(EM_ERR_INVALID, "em_step_many: raw actions are required");
+        rc = launch_env<false, false, ACT_RAW>(h, nullptr, resource_or_raw, nullptr, out, s, 0.5f, k_steps, history);
+        break;
+    case EM_ACTIONS_GREEDY:
+        if (!(greedy_share > 0.0f) || !(greedy_share <= 1.0f))
+            return em::fail(EM_ERR_INVALID, "em_step_many: resource share must be in (0, 1]");
+        rc = launch_env<false, false, ACT_GREEDY>(h, nullptr, nullptr, nullptr, out, s, greedy_share, k_steps, history);
+        break;
+    default: return em::fail(EM_ERR_INVALID, "em_step_many: unknown action mode %d", action_mode);
+    }
+    if (rc) return rc;
+    h->step += k_steps;
+    if (!h->explore_off) h->explore_counter += k_steps;   // MRRL.PY:467-468, once per step
     return EM_OK;
 }
 

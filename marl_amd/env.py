@@ -208,6 +208,56 @@ class BatchedEdgeSimGym:
                                               _stream_ptr(self.device)), "em_step_greedy")
         return self._step_result()
 
+    def step_many(self, k_steps: int, placement: torch.Tensor | None = None, resource: torch.Tensor | None = None,
+                  raw: torch.Tensor | None = None, greedy_share: float | None = None, obs_history: bool = False):
+        """``k_steps`` consecutive steps in ONE launch for open-loop actions (``em_step_many``): ``placement``/``resource``
+        ``[K, B, N]``, or ``raw`` ``[K, B, N, N+1]``, or ``greedy_share`` for the greedy baseline's policy.  The state
+        records stay on chip between the steps.  Returns ``(obs, reward[K, B] f64, done[K, B] u8, info)`` where ``obs`` is
+        the last step's observation tensor, or ``[K, B, N, N+4]`` with ``obs_history=True`` (then ``info["active"]`` /
+        ``info["rank"]`` carry the step dimension too); ``info["reward_raw"]``/``info["emitted"]`` are ``[K, B]``."""
+        B, n, K, d = self.n_envs, self.n_nodes, int(k_steps), self.device
+        modes = (placement is not None) + (raw is not None) + (greedy_share is not None)
+        if modes != 1:
+            raise ValueError("give exactly one of placement+resource, raw, greedy_share")
+        pl_ptr = rs_ptr = None
+        share = 0.5
+        if placement is not None:
+            if resource is None or placement.dtype != torch.int32 or resource.dtype != torch.float32 or \
+                    tuple(placement.shape) != (K, B, n) or tuple(resource.shape) != (K, B, n) or \
+                    not (placement.is_contiguous() and resource.is_contiguous()) or placement.device != d or resource.device != d:
+                raise ValueError(f"placement (int32) and resource (float32) must be contiguous [{K}, {B}, {n}] tensors on {d}")
+            mode, pl_ptr, rs_ptr = 0, placement.data_ptr(), resource.data_ptr()
+        elif raw is not None:
+            if raw.dtype != torch.float32 or tuple(raw.shape) != (K, B, n, n + 1) or not raw.is_contiguous() or raw.device != d:
+                raise ValueError(f"raw actions must be a contiguous float32 [{K}, {B}, {n}, {n + 1}] tensor on {d}")
+            mode, rs_ptr = 1, raw.data_ptr()
+        else:
+            mode, share = 2, float(greedy_share)
+        f64, u8 = torch.float64, torch.uint8
+        hist = {"reward": torch.zeros((K, B), dtype=f64, device=d), "reward_raw": torch.zeros((K, B), dtype=f64, device=d),
+                "emitted": torch.zeros((K, B), dtype=u8, device=d), "done": torch.zeros((K, B), dtype=u8, device=d)}
+        o = _lib.EmStepOut()
+        o.reward_seen, o.reward = hist["reward"].data_ptr(), hist["reward_raw"].data_ptr()
+        o.emitted, o.done = hist["emitted"].data_ptr(), hist["done"].data_ptr()
+        history = 1
+        if obs_history:
+            obs = torch.empty((K, B, n, n + 4), dtype=torch.float32, device=d)
+            active = torch.empty((K, B), dtype=torch.int64, device=d)
+            rank = torch.empty((K, B, n), dtype=torch.int8, device=d)
+            history |= 2
+        else:
+            obs, active, rank = self.obs, self.active, self.rank
+        o.obs, o.active, o.rank = obs.data_ptr(), active.data_ptr(), rank.data_ptr()
+        with torch.cuda.device(d):
+            _lib.check(self._L.em_step_many(self._h, K, mode, pl_ptr, rs_ptr, share, history, C.byref(o), _stream_ptr(d)),
+                       "em_step_many")
+        if obs_history:   # keep the environment's own "current observation" buffers in step with the state
+            self.obs.copy_(obs[-1]); self.active.copy_(active[-1]); self.rank.copy_(rank[-1])
+        self.reward.copy_(hist["reward"][-1]); self.reward_raw.copy_(hist["reward_raw"][-1])
+        self.emitted.copy_(hist["emitted"][-1]); self.done.copy_(hist["done"][-1])
+        info = {"reward_raw": hist["reward_raw"], "emitted": hist["emitted"], "rank": rank, "active": active}
+        return obs, hist["reward"], hist["done"], info
+
     def episode_metrics(self) -> torch.Tensor:
         out = torch.zeros((self.n_envs, 6), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):

@@ -338,3 +338,57 @@ def test_other_topologies_and_heavy_arrivals_match_c_restatement(n, rates, B, pa
     np.testing.assert_allclose(m, rm, rtol=1e-12, atol=0)
     if rates[0] >= 400 and n <= 17:
         assert max_arrivals > 8, "configuration failed to reach the sequential arrival tail"
+
+
+@pytest.mark.parametrize("lanes", [16, 1])
+@pytest.mark.parametrize("mode", ["dict", "raw", "greedy"])
+def test_step_many_equals_single_steps(mode, lanes):
+    """em_step_many (k steps in one launch, records resident in LDS, scalar wavefront one step ahead) is bit-identical
+    to k launches of em_step / em_step_raw / em_step_greedy: per-step rewards, done flags, observation history, final
+    state, exploration counter and episode metrics; exploration is ON so the per-step epsilon is exercised."""
+    from marl_amd.env import BatchedEdgeSimGym
+    T, B, n = 64, 83, 10
+    cfg = eo.default_config()
+    cfg.update(episode_length=T)
+    cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 40}
+    seed = 4242
+    rs = np.random.RandomState(3)
+    pl = torch.as_tensor(rs.randint(-1, n, size=(T, B, n)).astype(np.int32)).cuda()
+    rsrc = torch.as_tensor(rs.uniform(0.1, 1.0, size=(T, B, n)).astype(np.float32)).cuda()
+    raw = torch.as_tensor(rs.normal(0, 1, size=(T, B, n, n + 1)).astype(np.float32)).cuda()
+
+    def make():
+        e = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=seed, latency_log_capacity=T * n)
+        e.set_lanes_per_env(lanes)
+        e.reset()
+        return e
+
+    one = make()
+    rew1, done1, obs1 = [], [], []
+    for t in range(T):
+        if mode == "dict":
+            o, r, d, _, info = one.step(pl[t], rsrc[t])
+        elif mode == "raw":
+            o, r, d, _, info = one.step_raw(raw[t])
+        else:
+            o, r, d, _, info = one.step_greedy(0.5)
+        rew1.append(r.clone()); done1.append(d.clone()); obs1.append(o.clone())
+    many = make()
+    chunks = [(0, 1), (1, 8), (8, 41), (41, T)]          # 1, 7, 33 and 23 steps per launch
+    rewm, donem, obsm = [], [], []
+    for a, b in chunks:
+        kw = {"dict": dict(placement=pl[a:b].contiguous(), resource=rsrc[a:b].contiguous()),
+              "raw": dict(raw=raw[a:b].contiguous()), "greedy": dict(greedy_share=0.5)}[mode]
+        o, r, d, info = many.step_many(b - a, obs_history=(a == 8), **kw)
+        rewm.append(r); donem.append(d)
+        obsm.append(o if o.dim() == 4 else None)
+        assert torch.equal(many.obs, obs1[b - 1]), (a, b)          # last observation of the chunk
+    assert torch.equal(torch.cat(rewm), torch.stack(rew1)) and torch.equal(torch.cat(donem), torch.stack(done1))
+    assert torch.equal(obsm[2], torch.stack(obs1[8:41]))
+    s1, sm = one.get_state(), many.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], sm[k]), k
+    assert one.global_step_counter == many.global_step_counter == T
+    assert torch.equal(one.episode_metrics(), many.episode_metrics())
+    with pytest.raises(RuntimeError):
+        many.step_many(1, greedy_share=0.5)       # the episode is over
