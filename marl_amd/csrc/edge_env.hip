@@ -59,13 +59,18 @@ struct EnvParams {
     double eps;
     int32_t step_no;
     float greedy_share;          // resource share of the greedy policy (ACT_GREEDY)
-    int32_t k_steps, pad2;       // consecutive steps taken by this launch (em_step_many; 1 otherwise)
-    int64_t hist_stride;         // per-step stride (in environments) of reward/emitted/done outputs: 0 = overwrite
-    int64_t obs_hist_stride;     // same for obs/active/rank
-    int64_t explore_counter0;    // exploration step counter at the first step of the launch (MRRL.PY:122)
+    int32_t pad2;
     // step_no: 1-based index of the step being taken (all environments of a handle move together)
     uint32_t seed_lo, seed_hi, episode, env_offset;
     int64_t n_envs, lat_cap;
+};
+
+// Extra scalars of the several-steps-per-launch form (em_step_many); the single-step kernels never read them.
+struct MultiParams {
+    int32_t k_steps, pad;        // consecutive steps taken by this launch
+    int64_t hist_stride;         // per-step stride (in environments) of reward/emitted/done outputs: 0 = overwrite
+    int64_t obs_hist_stride;     // same for obs/active/rank
+    int64_t explore_counter0;    // exploration step counter at the first step of the launch (MRRL.PY:122)
 };
 
 // Per-handle constants, resident in HBM (read with scalar loads where they are used, which keeps them
@@ -203,6 +208,9 @@ enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512, EM_LANES_PACKED 
 #ifndef EM_ENV_MIN_WAVES
 #define EM_ENV_MIN_WAVES 6     // wavefronts per SIMD the register allocation aims for
 #endif
+#ifndef EM_ENV_MIN_WAVES_MULTI
+#define EM_ENV_MIN_WAVES_MULTI 4
+#endif
 
 // bits of a wavefront ballot that belong to group g of width gw (LPE == 0: the packed layout, gw = n_nodes < 64)
 template <int LPE>
@@ -247,8 +255,565 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     const int n_work = (int)(blockDim.x >> 6) - 1;
     const bool scalar_wave = wave == n_work;
     const int64_t env_b0 = (int64_t)blockIdx.x * (n_work * EPW);   // first environment of the workgroup
+    const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
+    double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [64] window per environment
+    int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
+
+    // worker coordinates (meaningless on the scalar wavefront)
+    const int g_raw = lane / GW, sl = lane - g_raw * GW;
+    const bool spare = g_raw >= EPW;                 // packed layout only: lanes past the last whole group
+    const int g = spare ? 0 : g_raw, gbase = g * GW; // (they shadow group 0 and never pass a valid/agent guard)
+    const int64_t env0 = env_b0 + (int64_t)wave * EPW;
+    const int n_valid = (scalar_wave || env0 >= p.n_envs) ? 0 : (int)((p.n_envs - env0) < EPW ? (p.n_envs - env0) : EPW);
+    const int64_t env = env0 + g;
+    const bool valid = !spare && g < n_valid;
+    const bool agent = valid && sl < n;
+    const uint32_t envid = p.env_offset + (uint32_t)env;
+
+    // LDS carve-up of a worker wavefront
+    unsigned char* wbase = smem + (scalar_wave ? 0 : wave) * p.wave_bytes;
+    unsigned char* rec = wbase + g * p.rec_bytes;
+    double* r_load = reinterpret_cast<double*>(rec);
+    double* r_wl = r_load + n;
+    double* r_data = r_wl + n;
+    double* r_ddl = r_data + n;
+    double* r_scal = r_ddl + n;
+    int32_t* r_queue = reinterpret_cast<int32_t*>(rec + rec_off_queue(n));
+    int32_t* r_int = reinterpret_cast<int32_t*>(rec + rec_off_int(n));
+    int8_t* r_rank = reinterpret_cast<int8_t*>(rec + rec_off_rank(n));
+    const int slots = n < 8 ? 8 : n;                   // latency/energy slots per environment (>= 8: batched reads)
+    int off = EPW * p.rec_bytes;
+    float* s_obs_w = reinterpret_cast<float*>(wbase + off);
+    float* s_obs = s_obs_w + g * p.obs_floats;
+    off += (EPW * p.obs_floats * 4 + 15) & ~15;
+    double* s_lat = reinterpret_cast<double*>(wbase + off) + g * slots;
+    off += EPW * slots * 8;
+    double* s_en = reinterpret_cast<double*>(wbase + off) + g * slots;
+    off += EPW * slots * 8;
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(wbase + off) + g;   // ranks of the acting agents
+    off += EPW * 8;
+    float* s_ratio = reinterpret_cast<float*>(wbase + off) + g * n;
+    off += EPW * n * 4;
+    int32_t* s_first = reinterpret_cast<int32_t*>(wbase + off) + g * n;   // first arrival index per decider
+
+    // values that live across the barrier
+    double reward = 0.0, t_now = 0.0, cap_me = 1.0, icap_me = 1.0;
+    int draws_lane = 0;
+    // arrivals drawn in parallel per step: 8 with 16+ lanes per environment, n/2 in the packed layout
+    const int par_philox = (LPE == 0) ? (GW / 2 < PAR_TASKS ? GW / 2 : PAR_TASKS) : PAR_TASKS;
+    // pre-drawn task of lane sl < par_philox (philox mode)
+    double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
+    int pre_dec = 0;
+
+    if (scalar_wave) {
+        // =========================== scalar wavefront: one environment per lane ===========================
+        STAMP(12);
+        const int64_t e = env_b0 + lane;
+        const bool v = lane < n_work * EPW && e < p.n_envs;
+        const uint32_t eid = p.env_offset + (uint32_t)e;
+        double t0 = 0.0;
+        if constexpr (!RESET) {
+            if (v) t0 = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
+        }
+        double rate_u = 0.0, dt_u = 0.0;
+        double pu[PRE_POIS_U] = {0.0};     // first uniforms of the Knuth loop, drawn while the clock loads
+        if constexpr (!TAPE) {
+            const uint4 b = philox(eid, p.episode, step_no, (P_DT << 24), p.seed_lo, p.seed_hi);
+            dt_u = u53(b.x, b.y);
+            rate_u = cc->rate_lo + cc->rate_span * u53(b.z, b.w);
+#pragma unroll
+            for (int i = 0; i < PRE_POIS_U / 2; ++i) {
+                const uint4 q = philox(eid, p.episode, step_no, (P_POIS << 24) | (uint32_t)i, p.seed_lo, p.seed_hi);
+                pu[2 * i] = u53(q.x, q.y);
+                pu[2 * i + 1] = u53(q.z, q.w);
+            }
+        }
+        double rate;
+        if (p.rate_mode == 3) rate = cc->rate_lo;      // degenerate range (MRRL.PY:222-223)
+        else if (p.rate_mode == 1) {
+            const double cyc = cc->cycle, icyc = cc->inv_cycle;   // cycle already clamped to >= 1e-6 (MRRL.PY:226)
+            const double phase = qdiv(exact_fmod_pos(t0, cyc, icyc), cyc, icyc);
+            // tape mode never uses the rate (dt and the arrival count come pre-drawn)
+            rate = cc->rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * cc->rate_span;
+        } else if (p.rate_mode == 2) {
+            if constexpr (TAPE) rate_u = v ? tape.rate_u[e] : 0.0;
+            rate = rate_u;
+        } else rate = cc->rate_mid;
+        const double rate_c = rate > 1e-6 ? rate : 1e-6;
+
+        double window;
+        if constexpr (RESET) window = cc->window0;
+        else {
+            double raw;
+            if constexpr (TAPE) raw = v ? tape.dt_raw[e] : 0.0;
+            else raw = (1.0 / rate_c) * (-det_log(1.0 - dt_u));
+            const double dt_min = cc->dt_min, dt_max = cc->dt_max;
+            window = raw < dt_min ? dt_min : (raw > dt_max ? dt_max : raw);   // MRRL.PY:247
+        }
+        STAMP(13);
+        int n_new = 0;
+        if constexpr (TAPE) {
+            n_new = v ? tape.n_arrivals[e] : 0;
+            if (n_new > tape.arrival_slots || n_new < 0) { atomicOr(err_flag, 2); n_new = 0; }
+        } else if (v) {
+            const double limit = det_exp(-(rate_c * window));
+            double prod = 1.0;
+            bool going = true;
+#pragma unroll
+            for (int i = 0; i < PRE_POIS_U; ++i) {   // Knuth multiplication method on the pre-drawn uniforms
+                prod = prod * pu[i];
+                going = going && prod > limit;
+                n_new += going ? 1 : 0;
+            }
+            if (going) {
+                uint4 b = make_uint4(0, 0, 0, 0);
+                for (uint32_t i = PRE_POIS_U;; ++i) {   // rare tail; ends at n_new == 4096 at the latest
+                    if ((i & 1u) == 0u) b = philox(eid, p.episode, step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
+                    const double u = (i & 1u) ? u53(b.z, b.w) : u53(b.x, b.y);
+                    prod = prod * u;
+                    if (prod > limit && n_new < 4096) ++n_new; else break;
+                }
+            }
+        }
+        s_win[lane] = window;
+        s_nnew[lane] = n_new;
+        STAMP(14);
+    } else {
+        // =========================== worker wavefront, part 1: placements ================================
+        STAMP(0);
+        // global loads first: actions, capacity tables, the records
+        int tgt_in = -1;
+        float res_in = 1.0f;
+        double ik_lane = 0.0;
+        if (agent) {
+            cap_me = cc->cap[sl];
+            icap_me = cc->inv_cap[sl];
+            ik_lane = cc->inv_k[sl + 1];
+            if constexpr (!RESET && ACT == ACT_DICT) { tgt_in = placement[env * n + sl]; res_in = resource[env * n + sl]; }
+            if constexpr (!RESET && ACT == ACT_RAW) {
+                const float* v = resource + (env * n + sl) * (int64_t)(n + 1);
+                bool all_zero = true, have_nan = false;
+                float best = v[0];
+                int bi = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float x = v[j];
+                    all_zero = all_zero && (fabsf(x) <= 1e-8f);              // np.allclose(logits, 0), MRRL.PY:292
+                    if (!have_nan && (x != x)) { have_nan = true; bi = j; }   // np.argmax returns the first NaN
+                    if (!have_nan && x > best) { best = x; bi = j; }
+                }
+                tgt_in = all_zero ? 0 : bi % n;                               // MRRL.PY:293-295
+                double nrm = ((double)v[n] + 1.0) / 2.0;                      // MRRL.PY:297-299
+                nrm = nrm < 0.0 ? 0.0 : (nrm > 1.0 ? 1.0 : nrm);
+                res_in = (float)(0.1 + 0.9 * nrm);
+            }
+        }
+        uint4* ldst = reinterpret_cast<uint4*>(wbase);
+        const int nvec = n_valid * p.rec_bytes / 16;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+        if constexpr (!RESET) {
+            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+            if (lane < nvec) v0 = src[lane];
+            if (lane + 64 < nvec) v1 = src[lane + 64];
+        }
+
+        // random numbers that depend only on (environment, step, lane): evaluated while the loads fly
+        double net_bw = 0.0, net_lat = 0.0, ex_u = 2.0, ex_res = 0.0;
+        int ex_tgt = 0;
+        if constexpr (!TAPE) {
+            if (sl < 2 * par_philox) {
+                // lanes 0..par-1: P_TASK_A of arrival sl (workload, data); lanes par..2par-1: P_TASK_B of arrival sl-par
+                const bool is_a = sl < par_philox;
+                const uint4 b = philox(envid, p.episode, step_no,
+                                       ((is_a ? P_TASK_A : P_TASK_B) << 24) | (uint32_t)(is_a ? sl : sl - par_philox),
+                                       p.seed_lo, p.seed_hi);
+                const double ra = (is_a ? cc->wl_lo : cc->ddl_lo) + (is_a ? cc->wl_span : cc->ddl_span) * u53(b.x, b.y);
+                const double rb = cc->data_lo + cc->data_span * u53(b.z, b.w);
+                const int rz = (int)__umulhi(b.z, (uint32_t)n);
+                pre_wl = ra;
+                pre_data = rb;
+                const int partner = gbase + (is_a ? sl + par_philox : sl - par_philox);
+                pre_offs = __shfl(ra, partner);           // lane j < par takes the deadline offset and the decider
+                pre_dec = __shfl(rz, partner);            // of arrival j from lane j + par
+            }
+            if constexpr (!RESET) {
+                if (agent) {
+                    const uint4 b = philox(envid, p.episode, step_no, (P_NET << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                    net_bw = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
+                    net_lat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
+                    if (p.explore) {
+                        const uint4 e1 = philox(envid, p.episode, step_no, (P_EXPL << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                        ex_u = u53(e1.x, e1.y);
+                        ex_tgt = (int)__umulhi(e1.z, (uint32_t)n);
+                        if (!(ex_u > p.eps)) {
+                            const uint4 e2 = philox(envid, p.episode, step_no, (P_EXPL_RES << 24) | (uint32_t)sl, p.seed_lo, p.seed_hi);
+                            ex_res = 0.1 + (1.0 - 0.1) * u53(e2.x, e2.y);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- stage in: records (zeros at reset), zeroed observation tile, per-step scratch -----------
+        const int nstage = RESET ? EPW * p.rec_bytes / 16 : nvec;
+        if (lane < nstage) ldst[lane] = v0;
+        if (lane + 64 < nstage) ldst[lane + 64] = v1;
+        if constexpr (RESET) {
+            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
+        }
+        {
+            uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
+            for (int i = lane; i < ((EPW * p.obs_floats * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
+            if (sl == 0) *s_mask = 0ull;
+            if (sl < n) s_first[sl] = 0x7fffffff;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        STAMP(1);
+
+        if constexpr (!RESET && ACT == ACT_GREEDY) {
+            // target = argmin(nodes_load / cpu_caps), first minimum (np.argmin), the same for every acting agent
+            double ratio = agent ? qdiv(r_load[sl], cap_me, icap_me) : __builtin_inf();
+            int idx = sl;
+            if constexpr (LPE == 0) {
+                const double mine = ratio;
+                for (int i = 0; i < GW; ++i) {       // packed groups are not a power of two: linear scan by shuffles
+                    const double o = __shfl(mine, gbase + i);
+                    if (o < ratio || (o == ratio && i < idx)) { ratio = o; idx = i; }
+                }
+            } else {
+#pragma unroll
+                for (int m = LPE / 2; m > 0; m >>= 1) {
+                    const double o = __shfl_xor(ratio, m);
+                    const int oi = __shfl_xor(idx, m);
+                    if (o < ratio || (o == ratio && oi < idx)) { ratio = o; idx = oi; }
+                }
+            }
+            tgt_in = agent ? idx : -1;
+            res_in = p.greedy_share;
+        }
+        if constexpr (!RESET) {
+            t_now = r_scal[S_TIME];
+            // ---- placement phase: per-agent quantities in parallel on the lanes (MRRL.PY:397-423) ----
+            const int rank = agent ? (int)r_rank[sl] : -1;
+            int tgt = tgt_in;
+            const bool acting = rank >= 0 && tgt >= 0 && tgt < n;
+            float res = acting ? res_in : 1.0f;
+            const double wl = acting ? r_wl[sl] : 1.0;
+            const double data = acting ? r_data[sl] : 1.0;
+            const double ddl = acting ? r_ddl[sl] : 0.0;
+            if (acting) atomicOr(s_mask, 1ull << rank);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long rmask = *s_mask;
+            // acting slot = number of acting agents that arrived earlier; k = acting agents of the environment
+            const int slot = acting ? __popcll(rmask & ((1ull << rank) - 1ull)) : -1;
+            const int k = valid ? __popcll(rmask) : 0;
+
+            if (p.explore && acting) {   // _maybe_apply_env_exploration, MRRL.PY:258-274
+                if constexpr (TAPE) ex_u = tape.explore_u[env * n + slot];
+                draws_lane += 1;
+                if (!(ex_u > p.eps)) {
+                    if constexpr (TAPE) {
+                        ex_tgt = tape.explore_tgt[env * n + slot];
+                        ex_res = tape.explore_res[env * n + slot];
+                        if (ex_tgt < 0 || ex_tgt >= n) { atomicOr(err_flag, 1); ex_tgt = 0; }
+                    }
+                    tgt = ex_tgt;
+                    res = (float)ex_res;
+                    draws_lane += 2;
+                }
+            }
+
+            double t_trans = 0.0;
+            if (acting && tgt != sl) {   // MRRL.PY:409-414
+                if constexpr (TAPE) { net_bw = tape.bw_u[env * n + slot]; net_lat = tape.net_lat[env * n + slot]; }
+                draws_lane += 2;
+                const double bw = net_bw * 1e6 / 8;
+                t_trans = (data / bw) + net_lat;
+            }
+            // capacity of the target server: held by lane `tgt` of this group
+            const int tl = gbase + (acting ? tgt : sl);
+            const double cap_t = __shfl(cap_me, tl), icap_t = __shfl(icap_me, tl);
+            const double alloc = cap_t * (double)res;        // MRRL.PY:418 (float64 * float32)
+            const double gcyc = qdiv(alloc, 1e9, 1e-9);
+            const double t_exec = wl / gcyc;                  // MRRL.PY:419
+            const double energy = wl * gcyc;                  // MRRL.PY:423
+            const double inc = t_exec * gcyc;                 // MRRL.PY:437
+
+            STAMP(2);
+            // ---- ordered chain over acting slots: queueing delay sees earlier placements (MRRL.PY:416,437)
+            bool viol = false;
+            for (int s = 0; __ballot(acting && slot >= s) != 0ull; ++s) {
+                if (acting && slot == s) {
+                    const double l = r_load[tgt];
+                    const double t_queue = qdiv(l, cap_t, icap_t);
+                    const double t_total = t_trans + t_queue + t_exec;
+                    viol = (t_now + t_total) > ddl;          // MRRL.PY:431
+                    s_lat[s] = t_total;
+                    s_en[s] = energy;
+                    r_load[tgt] = l + inc;
+                    r_queue[tgt] += 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int n_viol = __popcll(group_bits<LPE>(__ballot(viol), g, GW));
+
+            STAMP(3);
+            // ---- reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466) ----------------
+            const int tasks_before = r_int[I_TASKS];
+            double sum_lat, sum_en, acc_lat = r_scal[S_SUMLAT], acc_en = r_scal[S_SUMEN];
+            if (__ballot(k > 4) == 0ull) {
+                // common case: one batch of LDS reads, sums in numpy's order for fewer than 8 addends
+                const double a0 = s_lat[0], a1 = s_lat[1], a2 = s_lat[2], a3 = s_lat[3];
+                const double e0 = s_en[0], e1 = s_en[1], e2 = s_en[2], e3 = s_en[3];
+                double rl = -0.0, re = -0.0;
+                if (k > 0) { rl += a0; re += e0; acc_lat += a0; acc_en += e0; }
+                if (k > 1) { rl += a1; re += e1; acc_lat += a1; acc_en += e1; }
+                if (k > 2) { rl += a2; re += e2; acc_lat += a2; acc_en += e2; }
+                if (k > 3) { rl += a3; re += e3; acc_lat += a3; acc_en += e3; }
+                sum_lat = 0.0 + rl;
+                sum_en = 0.0 + re;
+            } else {
+                sum_lat = np_sum_small(s_lat, k);
+                sum_en = np_sum_small(s_en, k);
+                for (int i = 0; i < k; ++i) { acc_lat += s_lat[i]; acc_en += s_en[i]; }
+            }
+            if (k > 0) {
+                const double kd = (double)k, ik = __shfl(ik_lane, gbase + k - 1);
+                const double cost = (cc->w_lat * qdiv(sum_lat, kd, ik)) + (cc->w_en * qdiv(sum_en, kd, ik)) +
+                                    (cc->w_viol * (double)n_viol);
+                reward = -cost;
+            }
+            if (agent) {
+                if (out.step_latency) out.step_latency[env * n + sl] = sl < k ? s_lat[sl] : __builtin_nan("");
+                if (lat_log && sl < k) {
+                    const int64_t at = (int64_t)tasks_before + sl;
+                    if (at < p.lat_cap) lat_log[env * p.lat_cap + at] = s_lat[sl];
+                }
+            }
+            if (valid && sl == 0) {
+                r_scal[S_SUMLAT] = acc_lat;
+                r_scal[S_SUMEN] = acc_en;
+                r_int[I_TASKS] = tasks_before + k;
+                r_int[I_VIOL] += n_viol;
+                r_int[I_DONE] += k - n_viol;
+                if (lat_log) {
+                    const int64_t end = (int64_t)tasks_before + k;
+                    r_int[I_LOGGED] = (int32_t)(end < p.lat_cap ? end : p.lat_cap);
+                }
+            }
+        }
+        STAMP(4);
+    }
+
+    __syncthreads();   // the scalar wavefront's windows and arrival counts are in LDS
+    if (scalar_wave) return;
+
+    // =============================== worker wavefront, part 2: arrivals (MRRL.PY:340-383) ===============
+    STAMP(5);
+    const double window = s_win[wave * EPW + g];
+    const int n_new = valid ? s_nnew[wave * EPW + g] : 0;
+    float ratio_me = 0.0f;
+    if (agent) {
+        r_rank[sl] = -1;
+        ratio_me = (float)qdiv(r_load[sl], cap_me, icap_me);   // load/cap BEFORE this step's decay
+        s_ratio[sl] = ratio_me;
+    }
+    // arrivals 0..PAR-1 in parallel, arrival j on lane j of the group
+    const int PAR = TAPE ? (GW < 16 ? GW : 16) : par_philox;
+    const bool has = valid && sl < PAR && sl < n_new;
+    double a_wl = pre_wl, a_data = pre_data, a_offs = pre_offs;
+    int a_dec = pre_dec;
+    if constexpr (TAPE) {
+        if (has) {
+            const int64_t o = env * tape.arrival_slots + sl;
+            a_wl = tape.task_workload[o]; a_data = tape.task_data[o];
+            a_offs = tape.task_deadline_offset[o]; a_dec = tape.task_decider[o];
+            if (a_dec < 0 || a_dec >= n) { atomicOr(err_flag, 4); a_dec = 0; }
+        }
+    }
+    const double a_deadline = t_now + a_offs;              // MRRL.PY:217
+    if (has) atomicMin(&s_first[a_dec], sl);               // first arrival of each decider (MRRL.PY:358-362)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool is_new = has && s_first[a_dec] == sl;
+    const uint32_t new_bits = (uint32_t)group_bits<LPE>(__ballot(is_new), g, GW);
+    const int first_me = agent ? s_first[sl] : 0x7fffffff;
+    const int q_me = agent ? r_queue[sl] : 0;              // queue length BEFORE this call's bumps (MRRL.PY:311)
+    const bool pend_me = first_me != 0x7fffffff;
+    if (is_new) {                                          // MRRL.PY:361 and the task columns of _get_obs
+        r_rank[a_dec] = (int8_t)__popc(new_bits & ((1u << sl) - 1u));
+        r_wl[a_dec] = a_wl; r_data[a_dec] = a_data; r_ddl[a_dec] = a_deadline;
+        const double rem = a_deadline - t_now;
+        float* row = s_obs + a_dec * w;
+        row[2] = (float)a_data;
+        row[3] = (float)a_wl;
+        row[4] = (float)(rem > 0 ? rem : 0.0);
+    }
+    if (pend_me) { s_obs[sl * w] = ratio_me; s_obs[sl * w + 1] = (float)q_me; }
+    // the other servers' load ratios: every lane writes its own ratio into the rows of the pending agents
+    {
+        uint64_t pm = group_bits<LPE>(__ballot(pend_me), g, GW);
+        while (__ballot(pm != 0ull) != 0ull) {
+            if (pm != 0ull) {
+                const int r = __ffsll((unsigned long long)pm) - 1;
+                pm &= pm - 1ull;
+                if (agent && sl != r) s_obs[r * w + (sl < r ? sl + 5 : sl + 4)] = ratio_me;
+            }
+        }
+    }
+    if (has && !is_new) atomicAdd(&r_queue[a_dec], 1);    // MRRL.PY:359
+    int n_pending = __popc(new_bits);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    STAMP(6);
+    if (__ballot(n_new > PAR) != 0ull) {
+        // rare tail: arrivals beyond the parallel batch, one at a time in arrival order
+        for (int j = PAR;; ++j) {
+            const bool more = j < n_new;
+            if (__ballot(more) == 0ull) break;
+            if (more) {
+                double wl, data, offs;
+                int dec;
+                if constexpr (TAPE) {
+                    const int64_t o = env * tape.arrival_slots + j;
+                    wl = tape.task_workload[o]; data = tape.task_data[o];
+                    offs = tape.task_deadline_offset[o]; dec = tape.task_decider[o];
+                    if (dec < 0 || dec >= n) { atomicOr(err_flag, 4); dec = 0; }
+                } else {
+                    const uint4 a = philox(envid, p.episode, step_no, (P_TASK_A << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
+                    const uint4 b = philox(envid, p.episode, step_no, (P_TASK_B << 24) | (uint32_t)j, p.seed_lo, p.seed_hi);
+                    wl = cc->wl_lo + cc->wl_span * u53(a.x, a.y);
+                    data = cc->data_lo + cc->data_span * u53(a.z, a.w);
+                    offs = cc->ddl_lo + cc->ddl_span * u53(b.x, b.y);
+                    dec = (int)__umulhi(b.z, (uint32_t)n);
+                }
+                const double deadline = t_now + offs;          // MRRL.PY:217
+                const bool fresh = r_rank[dec] < 0;            // broadcast read, before any lane updates
+                const float q_now = (float)r_queue[dec];
+                if (sl == 0) {
+                    if (fresh) {                                // MRRL.PY:361
+                        r_rank[dec] = (int8_t)n_pending;
+                        r_wl[dec] = wl; r_data[dec] = data; r_ddl[dec] = deadline;
+                    } else r_queue[dec] += 1;                  // MRRL.PY:359
+                }
+                if (fresh) {                                    // _get_obs, MRRL.PY:307-324
+                    const double rem = deadline - t_now;
+                    for (int c = sl; c < w; c += GW) {
+                        float v;
+                        if (c == 0) v = s_ratio[dec];
+                        else if (c == 1) v = q_now;
+                        else if (c == 2) v = (float)data;
+                        else if (c == 3) v = (float)wl;
+                        else if (c == 4) v = (float)(rem > 0 ? rem : 0.0);
+                        else { const int i = c - 5; v = s_ratio[i < dec ? i : i + 1]; }
+                        s_obs[dec * w + c] = v;
+                    }
+                    n_pending += 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    STAMP(9);
+    // ---- decay, clock, outputs (MRRL.PY:364-375,444-459) --------------------------------------------
+    if constexpr (!RESET) {
+        if (agent) {
+            double l = r_load[sl] - cap_me * window;
+            if (!(l > 0)) l = 0.0;
+            r_load[sl] = l;
+            const int q = r_queue[sl] - 1;
+            r_queue[sl] = q > 0 ? q : 0;
+        }
+    }
+    const int rank_out = agent ? (int)r_rank[sl] : -1;
+    const uint64_t act_bits = group_bits<LPE>(__ballot(rank_out >= 0), g, GW);
+    if (out.n_draws) {
+        int d = draws_lane;
+        if constexpr (LPE == 0) {
+            const int mine = d;
+            d = 0;
+            for (int i = 0; i < GW; ++i) d += __shfl(mine, gbase + i);
+        } else {
+            for (int m = LPE / 2; m > 0; m >>= 1) d += __shfl_xor(d, m, LPE);
+        }
+        // once per environment: rate (random mode), window (step only), arrival count, 4 per arrival
+        const int draws_env = (p.rate_mode == 2 ? 1 : 0) + (RESET ? 0 : 1) + 1 + 4 * n_new;
+        if (valid && sl == 0) out.n_draws[env] = d + draws_env;
+    }
+    if (valid && sl == 0) {
+        if constexpr (!RESET) {
+            r_scal[S_TIME] = t_now + window;               // delta_t > 0 always: dt_min > 0
+            r_scal[S_ELAPSED] = r_scal[S_ELAPSED] + window;
+            r_int[I_STEP] = (int32_t)step_no;
+            if (out.reward) out.reward[env] = reward;
+            if (out.emitted) out.emitted[env] = n_pending > 0;
+            if (out.reward_seen) out.reward_seen[env] = n_pending > 0 ? reward : 0.0;
+            if (out.done) out.done[env] = (int32_t)step_no >= p.horizon;
+        }
+        r_int[I_PENDING] = n_pending;
+        out.active[env] = act_bits;
+    }
+    if (agent && out.rank) out.rank[env * n + sl] = (int8_t)rank_out;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    STAMP(10);
+    // ---- stage out: records and observation tile, 16-byte lane-linear stores -------------------------
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wbase);
+        uint4* dst = reinterpret_cast<uint4*>(state + env0 * p.rec_bytes);
+        for (int i = lane; i < n_valid * p.rec_bytes / 16; i += 64) dst[i] = src[i];
+        const int64_t fbase = env0 * p.obs_floats;
+        const int nfl = n_valid * p.obs_floats;
+        float* gobs = out.obs + fbase;
+        if ((fbase & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(s_obs_w);
+            float4* d4 = reinterpret_cast<float4*>(gobs);
+            for (int i = lane; i < (nfl >> 2); i += 64) d4[i] = s4[i];
+            for (int i = (nfl & ~3) + lane; i < nfl; i += 64) gobs[i] = s_obs_w[i];
+        } else {
+            for (int i = lane; i < nfl; i += 64) gobs[i] = s_obs_w[i];
+        }
+    }
+    STAMP(11);
+}
+
+// The several-steps-per-launch form of env_kernel (em_step_many): the same step, inside a loop over the steps of the
+// launch.  The records stay in LDS between the steps and the scalar wavefront, which owns the environments' clocks,
+// runs one step ahead of the workers through a two-deep buffer.  It is a separate kernel on purpose: folding the
+// loop into env_kernel cost the single-step launch 15-20 % (longer live ranges, spills), and this one gets the larger
+// register budget its loop-carried values need.  TAPE/RESET/MULTI are kept as constants so the two bodies stay
+// comparable line by line; any change to the step arithmetic must be made in both.
+template <int LPE, int ACT, bool TAPE = false, bool RESET = false, bool MULTI = true>
+__global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES_MULTI) void env_multi_kernel(const EnvParams p, const MultiParams mp, unsigned char* __restrict__ state,
+                                                  const EnvConst* __restrict__ cc,
+                                                  const int32_t* __restrict__ placement,
+                                                  const float* __restrict__ resource, const em_tape tape,
+                                                  const em_step_out out, double* __restrict__ lat_log,
+                                                  int32_t* __restrict__ err_flag)
+{
+    // LPE = 16/32/64: power-of-two lane groups.  LPE = 0: PACKED groups of exactly n lanes (n = 10: six
+    // environments per wavefront instead of four); lanes beyond the last whole group idle.  Identical results.
+    const int GW = LPE ? LPE : p.n;      // lanes per environment
+    const int EPW = 64 / GW;             // environments per worker wavefront
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int n = p.n, w = n + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_work = (int)(blockDim.x >> 6) - 1;
+    const bool scalar_wave = wave == n_work;
+    const int64_t env_b0 = (int64_t)blockIdx.x * (n_work * EPW);   // first environment of the workgroup
     const uint32_t step_first = RESET ? 0u : (uint32_t)p.step_no;
-    const int K = RESET ? 1 : p.k_steps;            // consecutive steps of this launch; the records stay in LDS
+    const int K = MULTI ? mp.k_steps : 1;           // consecutive steps of this launch; the records stay in LDS
+    const int64_t hist_stride = MULTI ? mp.hist_stride : 0, obs_hist_stride = MULTI ? mp.obs_hist_stride : 0;
     double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [2][64] window per environment
     int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 128);                 // [2][64] arrivals per environment
 
@@ -292,11 +857,11 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     // =========================== scalar wavefront: one environment per lane ===========================
     // It owns each environment's clock for the launch (t(k+1) = t(k) + window(k), the very sum the workers store),
     // so with several steps per launch it runs one step ahead of the workers; results go to a two-deep LDS buffer.
-    const int64_t e = env_b0 + lane;
-    const bool v = scalar_wave && lane < n_work * EPW && e < p.n_envs;
-    const uint32_t eid = p.env_offset + (uint32_t)e;
     double sc_t = 0.0;
     auto scalar_step = [&](uint32_t step_no, int buf) {
+        const int64_t e = env_b0 + lane;
+        const bool v = lane < n_work * EPW && e < p.n_envs;
+        const uint32_t eid = p.env_offset + (uint32_t)e;
         const double t0 = sc_t;
         double rate_u = 0.0, dt_u = 0.0;
         double pu[PRE_POIS_U] = {0.0};     // first uniforms of the Knuth loop, drawn while the clock loads
@@ -363,13 +928,6 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         sc_t = t0 + window;          // the clock of the next step (workers add the same window, MRRL.PY:444-447)
         STAMP(14);
     };
-    if (scalar_wave) {
-        STAMP(12);
-        if constexpr (!RESET) {
-            if (v) sc_t = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
-        }
-        scalar_step(step_first, 0);
-    }
 
     // worker values that persist over the launch
     double cap_me = 1.0, icap_me = 1.0, ik_lane = 0.0;
@@ -385,20 +943,32 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     double pre_wl = 0.0, pre_data = 0.0, pre_offs = 0.0;
     int pre_dec = 0;
     // epsilon of this step, _get_current_epsilon (MRRL.PY:249-256)
-    double eps_k = 0.0;
-    if (p.explore) {
-        double frac = (double)(p.explore_counter0 + ks) / cc->eps_span;
-        if (frac > 1.0) frac = 1.0;
-        eps_k = cc->eps_init - (cc->eps_init - cc->eps_final) * frac;
+    double eps_k = p.eps;            // single step: evaluated on the host (same float64 formula)
+    if constexpr (MULTI) {
+        if (p.explore) {
+            double frac = (double)(mp.explore_counter0 + ks) / cc->eps_span;
+            if (frac > 1.0) frac = 1.0;
+            eps_k = cc->eps_init - (cc->eps_init - cc->eps_final) * frac;
+        }
     }
 
-    if (!scalar_wave) {
+    if (scalar_wave) {
+        if (ks == 0) {
+            STAMP(12);
+            if constexpr (!RESET) {
+                const int64_t e = env_b0 + lane;
+                if (lane < n_work * EPW && e < p.n_envs)
+                    sc_t = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
+            }
+            scalar_step(step_first, 0);
+        }
+    } else {
         // =========================== worker wavefront, part 1: placements ================================
         STAMP(0);
         // global loads first: actions, capacity tables, the records
         int tgt_in = -1;
         float res_in = 1.0f;
-        const int64_t aenv = env + (int64_t)ks * p.n_envs;      // row of this step in [k_steps][n_envs] action arrays
+        const int64_t aenv = MULTI ? env + (int64_t)ks * p.n_envs : env;   // row of this step in [k_steps][n_envs] action arrays
         if (agent) {
             if (ks == 0) {
                 cap_me = cc->cap[sl];
@@ -776,16 +1346,16 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             r_scal[S_TIME] = t_now + window;               // delta_t > 0 always: dt_min > 0
             r_scal[S_ELAPSED] = r_scal[S_ELAPSED] + window;
             r_int[I_STEP] = (int32_t)step_no;
-            const int64_t he = env + (int64_t)ks * p.hist_stride;
+            const int64_t he = env + (int64_t)ks * hist_stride;
             if (out.reward) out.reward[he] = reward;
             if (out.emitted) out.emitted[he] = n_pending > 0;
             if (out.reward_seen) out.reward_seen[he] = n_pending > 0 ? reward : 0.0;
             if (out.done) out.done[he] = (int32_t)step_no >= p.horizon;
         }
         r_int[I_PENDING] = n_pending;
-        out.active[env + (int64_t)ks * p.obs_hist_stride] = act_bits;
+        out.active[env + (int64_t)ks * obs_hist_stride] = act_bits;
     }
-    if (agent && out.rank) out.rank[(env + (int64_t)ks * p.obs_hist_stride) * n + sl] = (int8_t)rank_out;
+    if (agent && out.rank) out.rank[(env + (int64_t)ks * obs_hist_stride) * n + sl] = (int8_t)rank_out;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -796,8 +1366,8 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         uint4* dst = reinterpret_cast<uint4*>(state + env0 * p.rec_bytes);
         for (int i = lane; i < n_valid * p.rec_bytes / 16; i += 64) dst[i] = src[i];
     }
-    if (ks == K - 1 || p.obs_hist_stride != 0) {
-        const int64_t fbase = (env0 + (int64_t)ks * p.obs_hist_stride) * p.obs_floats;
+    if (ks == K - 1 || obs_hist_stride != 0) {
+        const int64_t fbase = (env0 + (int64_t)ks * obs_hist_stride) * p.obs_floats;
         const int nfl = n_valid * p.obs_floats;
         float* gobs = out.obs + fbase;
         if ((fbase & 3) == 0) {
@@ -968,9 +1538,14 @@ EnvParams make_params(const em_handle* h, int lanes)
     wb += epw * 8;                 // acting-rank masks
     wb += 2 * epw * p.n * 4;       // load ratios, first arrival per decider
     p.wave_bytes = (wb + 15) & ~15;
-    p.eps = 0.0;                                   // epsilon is evaluated per step inside the kernel
-    p.explore_counter0 = h->explore_counter;
-    p.k_steps = 1;
+    // _get_current_epsilon, MRRL.PY:249-256 (the several-steps-per-launch kernel re-evaluates it per step)
+    double eps = 0.0;
+    if (!h->explore_off) {
+        double frac = (double)h->explore_counter / (double)(c.decay_steps > 1 ? c.decay_steps : 1);
+        if (frac > 1.0) frac = 1.0;
+        eps = c.initial_epsilon - (c.initial_epsilon - c.final_epsilon) * frac;
+    }
+    p.eps = eps;
     p.seed_lo = (uint32_t)h->seed; p.seed_hi = (uint32_t)(h->seed >> 32);
     p.episode = h->episode;
     p.step_no = h->step + 1;
@@ -987,31 +1562,47 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     const int lanes = h->lanes;
     EnvParams p = make_params(h, lanes);
     p.greedy_share = greedy_share;
-    p.k_steps = k_steps;
-    p.hist_stride = (history & EM_HISTORY_REWARDS) ? h->n_envs : 0;
-    p.obs_hist_stride = (history & EM_HISTORY_OBS) ? h->n_envs : 0;
+    MultiParams mp;
+    std::memset(&mp, 0, sizeof mp);
+    mp.k_steps = k_steps;
+    mp.hist_stride = (history & EM_HISTORY_REWARDS) ? h->n_envs : 0;
+    mp.obs_hist_stride = (history & EM_HISTORY_OBS) ? h->n_envs : 0;
+    mp.explore_counter0 = h->explore_counter;
     const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
     // the scalar wavefront serves one environment per lane: at most 64 environments per workgroup
     const int n_work = (h->wg_waves - 1) * epw <= 64 ? h->wg_waves - 1 : (64 / epw > 0 ? 64 / epw : 1);
     const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
     const int64_t blocks = (h->n_envs + epb - 1) / epb;
-    const size_t lds = (size_t)p.wave_bytes * n_work + 2 * 64 * 12;   // + two-deep window/arrival-count buffers
+    // + the scalar wavefront's window/arrival-count buffers (two-deep in the several-steps kernel)
+    const size_t lds = (size_t)p.wave_bytes * n_work + (k_steps > 1 ? 2 : 1) * 64 * 12;
     if (lds > 160 * 1024) return em::fail(EM_ERR_INVALID, "n_nodes too large for the LDS tile (%zu bytes)", lds);
     em_tape tp;
     std::memset(&tp, 0, sizeof tp);
     if (tape) tp = *tape;
     const dim3 grid((unsigned)blocks), block(64 * (n_work + 1));
-#define EM_LAUNCH(L)                                                                                              \
-    hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT>), grid, block, lds, s, p, h->d_state, h->d_const, placement, \
-                       resource, tp, *out, h->d_lat_log, h->d_err)
-    if (lds > 64 * 1024) {
-        hipError_t e = hipSuccess;
-        if (lanes == EM_LANES_PACKED) e = hipFuncSetAttribute((const void*)env_kernel<0, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else if (lanes == 16) e = hipFuncSetAttribute((const void*)env_kernel<16, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else if (lanes == 32) e = hipFuncSetAttribute((const void*)env_kernel<32, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else e = hipFuncSetAttribute((const void*)env_kernel<64, TAPE, RESET, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");
-    }
+#define EM_LAUNCH(L)                                                                                                   \
+    do {                                                                                                               \
+        if (k_steps > 1) {                                                                                             \
+            if constexpr (!TAPE && !RESET) {                                                                           \
+                if (lds > 64 * 1024) {                                                                                 \
+                    const hipError_t e = hipFuncSetAttribute((const void*)env_multi_kernel<L, ACT>,                   \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+                    if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                \
+                }                                                                                                      \
+                hipLaunchKernelGGL((env_multi_kernel<L, ACT>), grid, block, lds, s, p, mp, h->d_state, h->d_const,    \
+                                   placement, resource, tp, *out, h->d_lat_log, h->d_err);                             \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            if (lds > 64 * 1024) {                                                                                     \
+                const hipError_t e = hipFuncSetAttribute((const void*)env_kernel<L, TAPE, RESET, ACT>,                \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+                if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                    \
+            }                                                                                                          \
+            hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT>), grid, block, lds, s, p, h->d_state, h->d_const,     \
+                               placement, resource, tp, *out, h->d_lat_log, h->d_err);                                 \
+        }                                                                                                              \
+    } while (0)
+    if (k_steps > 1 && (TAPE || RESET)) return em::fail(EM_ERR_INVALID, "several steps per launch need the in-kernel random stream");
     if (lanes == EM_LANES_PACKED) EM_LAUNCH(0);
     else if (lanes == 16) EM_LAUNCH(16);
     else if (lanes == 32) EM_LAUNCH(32);

@@ -65,6 +65,35 @@ int main(int argc, char** argv)
         sc[1] += (double)(st[13] - st[12]);
         sc[2] += (double)(st[14] - st[13]);
     }
+    if (argc > 5) {
+        // fused mode: K steps per launch, stamps of the LAST step of the launch
+        const int Kf = atoi(argv[5]);
+        std::vector<int32_t> plk((size_t)Kf * B * n);
+        std::vector<float> rsk((size_t)Kf * B * n);
+        for (size_t i = 0; i < plk.size(); ++i) { plk[i] = pl[i % (B * n)]; rsk[i] = rs[i % (B * n)]; }
+        int32_t* d_plk; float* d_rsk; double* d_rk; uint8_t* d_dk;
+        hipMalloc(&d_plk, plk.size() * 4); hipMalloc(&d_rsk, rsk.size() * 4); hipMalloc(&d_rk, (size_t)Kf * B * 8); hipMalloc(&d_dk, (size_t)Kf * B);
+        hipMemcpy(d_plk, plk.data(), plk.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(d_rsk, rsk.data(), rsk.size() * 4, hipMemcpyHostToDevice);
+        em_step_out o2 = out;
+        o2.reward_seen = d_rk; o2.done = d_dk;
+        em_reset(h, nullptr, 0, 0, &out, nullptr);
+        for (int i = 0; i < 10; ++i) acc[i] = 0;
+        sc[0] = sc[1] = sc[2] = 0;
+        hipEventRecord(e0, nullptr);
+        const int reps = 3;
+        for (int r = 0; r < reps; ++r) {
+            if (em_step_many(h, Kf, EM_ACTIONS_DICT, d_plk, d_rsk, 0.5f, EM_HISTORY_REWARDS, &o2, nullptr)) { printf("many: %s\n", em_last_error()); return 1; }
+        }
+        hipEventRecord(e1, nullptr);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("fused K=%d: %.2f us/step\n", Kf, ms * 1e3 / (reps * Kf));
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(em_stamps), sizeof st);
+        for (int i = 1; i < 10; ++i) acc[i] = (double)(st[seq[i]] - st[seq[i - 1]]) * R;
+        sc[1] = (double)(st[13] - st[12]) * R; sc[2] = (double)(st[14] - st[13]) * R; sc[0] = 0;
+        printf("  next step's STAMP(0) - this STAMP(11) not shown; loop period is the sum below\n");
+    }
     double tot = 0;
     for (int i = 1; i < 10; ++i) { printf("  %-22s %8.0f cycles\n", names[i], acc[i] / R); tot += acc[i] / R; }
     printf("  %-22s %8.0f cycles (s_memtime ticks)\n", "worker total", tot);
