@@ -215,6 +215,50 @@ def time_env_steps(device, rank, world, B, steps, warmup):
     return elapsed, dev_ms, n, T, record_bytes
 
 
+def fused_leg(device, rank, world, B, k_steps=250, launches=8):
+    """em_step_many: k_steps consecutive steps per launch on pre-generated actions (open-loop callers: scripted or
+    random actions, the greedy baseline).  Same workload as the headline otherwise; reported beside it, not as `value`."""
+    import torch.distributed as dist
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = dict(ENV_CONFIG)
+    cfg["disable_env_exploration"] = True
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B, latency_log_capacity=0)
+    n, T = env.n_nodes, env.episode_len
+    gen = torch.Generator(device=device).manual_seed(4321 + rank)
+    pl = torch.randint(0, n, (k_steps, B, n), device=device, generator=gen, dtype=torch.int32)
+    rs = (torch.rand((k_steps, B, n), device=device, generator=gen) * 0.9 + 0.1).contiguous()
+    per_episode = T // k_steps
+
+    def run(count):
+        for i in range(count):
+            if i % per_episode == 0:
+                env.reset()
+            env.step_many(k_steps, placement=pl, resource=rs)
+
+    run(per_episode)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(launches)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.close()
+    steps = launches * k_steps
+    return {"entry_point": "em_step_many", "steps_per_launch": k_steps, "n_envs_per_gpu": B, "steps": steps,
+            "value": world * B * n * steps / elapsed, "unit": "agent-steps/s", "us_per_step": elapsed * 1e6 / steps,
+            "outputs": "reward/done history [k][B] + last observation", "note": "state records stay in LDS between steps"}
+
+
 def traffic_for(B):
     """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -256,6 +300,9 @@ def main():
         k = max(200, args.steps // 4)
         e2, d2, _, _, _ = time_env_steps(device, rank, world, 65536, k, max(20, args.warmup // 4))
         scale = (65536, k, e2, d2)
+    fused = None
+    if not args.no_scale_point:
+        fused = fused_leg(device, rank, world, B)
     mappo = None
     if not args.no_mappo:
         mappo = mappo_leg(device, rank, world, args.mappo_envs)
@@ -298,6 +345,8 @@ def main():
                                    "roofline": {"bound": "hbm", "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": s_ach / HBM_PEAK_GBS, "traffic": traffic_for(sb),
                                                 "bytes_per_launch": s_bytes}}
+        if fused is not None:
+            line["fused_steps"] = fused
         if mappo is not None:
             line["mappo"] = mappo
         print(json.dumps(line), flush=True)

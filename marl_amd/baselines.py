@@ -26,8 +26,7 @@ def run_greedy_baseline(seed, num_episodes=100, n_envs=None, device="cuda:0", co
     while played < num_episodes:
         env.reset(seed=seed + played) if first else env.reset()
         first = False
-        for _ in range(env.episode_len):
-            env.step_greedy(0.5)
+        env.step_many(env.episode_len, greedy_share=0.5)     # the whole episode in one launch, policy in the kernel
         m = env.episode_metrics()
         has_final = env.active != 0
         take = min(B, num_episodes - played)
