@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 2
+#define EM_ABI_VERSION 3
 
 typedef enum em_status {
     EM_OK = 0,
@@ -159,6 +159,55 @@ int em_set_lanes_per_env(em_handle *h, int lanes);
  * scalar wavefront, 2..8); 0 restores the default.  Results do not depend on it. */
 int em_set_workgroup_waves(em_handle *h, int waves);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Scaled topology: D decider agents over S = cfg->n_nodes edge servers.
+ *
+ * The reference only knows deciders == servers (MRRL.PY:150,153,162,355).  This is the build's generalisation of
+ * the same step: decider d is attached to home server d mod S ("local" placement <=> target == home, MRRL.PY:409),
+ * arrivals pick a decider uniformly in [0, D) (MRRL.PY:355), a later arrival for a busy decider bumps the queue of its
+ * home server (MRRL.PY:358-359), the observation of decider d is _get_obs (MRRL.PY:307-324) seen from its home server
+ * (width S + 4), exploration targets are servers (MRRL.PY:271).  With D == S it is the reference step bit for bit
+ * (tests/test_scaled_gpu.py compares it with em_step).  Random numbers: the in-kernel Philox stream only.
+ *
+ * Outputs are COMPACT: at most EMS_PENDING_CAP deciders can hold a task at once (one per arrival of a step), so
+ * the library returns the pending list in arrival order instead of a dense [D][S+4] tensor that is >99 % zeros.
+ * ---------------------------------------------------------------------------------------------- */
+#define EMS_PENDING_CAP 64
+#define EMS_MAX_DECIDERS 4096
+
+typedef struct ems_handle ems_handle;
+
+typedef struct ems_step_out {
+    int32_t *n_pending;     /* [n_envs] deciders holding a task after the call (keys of the new obs dict)     */
+    int32_t *pend_decider;  /* [n_envs][EMS_PENDING_CAP] decider ids in arrival order (obs dict insertion order) */
+    float *pend_obs;        /* [n_envs][EMS_PENDING_CAP][S+4] observation rows of those deciders (_get_obs)      */
+    double *reward;         /* [n_envs] _calculate_reward (MRRL.PY:326-338); may be NULL                        */
+    double *reward_seen;    /* [n_envs] 0 when the new obs set is empty (mappo_trainer.py:209-212); may be NULL  */
+    uint8_t *emitted;       /* [n_envs] rewards dict non-empty (MRRL.PY:454-455); may be NULL                   */
+    uint8_t *done;          /* [n_envs] dones["__all__"] (MRRL.PY:459); may be NULL                             */
+    double *step_latency;   /* [n_envs][EMS_PENDING_CAP] t_total per acting slot, NaN beyond; may be NULL         */
+} ems_step_out;
+
+/* EdgeSimGym.__init__ (MRRL.PY:124-186) with n_deciders agents over cfg->n_nodes servers. */
+int ems_create(const em_config *cfg, int32_t n_deciders, int64_t n_envs, int device_id, uint64_t seed,
+               uint64_t env_offset, int64_t latency_log_capacity, ems_handle **out);
+int ems_destroy(ems_handle *h);
+/* EdgeSimGym.reset (MRRL.PY:188-212). */
+int ems_reset(ems_handle *h, int has_seed, uint64_t seed, const ems_step_out *out, void *stream);
+/* EdgeSimGym.step (MRRL.PY:386-521).  actions_by_slot == 0: placement/resource are [n_envs][n_deciders] (indexed by
+ * decider, the dict form of MRRL.PY:280-281); != 0: [n_envs][EMS_PENDING_CAP] aligned with the pending list the
+ * previous call returned.  placement = target server, negative = no action for that decider. */
+int ems_step(ems_handle *h, const int32_t *placement, const float *resource, int actions_by_slot,
+             const ems_step_out *out, void *stream);
+/* Episode metrics (MRRL.PY:470-504), out6 as em_episode_metrics. */
+int ems_episode_metrics(ems_handle *h, double *out6, void *stream);
+int ems_set_exploration(ems_handle *h, int disable_env_exploration, int64_t global_step_counter);
+int64_t ems_get_exploration_counter(const ems_handle *h);
+/* Host copies for tests: load/queue [n_envs][S] f64, sim_time/elapsed [n_envs], step [n_envs], counts [n_envs][3]. */
+int ems_get_state(ems_handle *h, double *load, double *queue, double *sim_time, double *elapsed, int32_t *step,
+                  int64_t *counts, void *stream);
+int64_t ems_record_bytes(const ems_handle *h);
 
 /* ------------------------------------------------------------------------------------------------
  * MAPPO side (reference mappo_algorithm.py / mappo_trainer.py)

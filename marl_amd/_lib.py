@@ -14,7 +14,7 @@ from .config import EmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class EmTape(C.Structure):
@@ -35,6 +35,12 @@ class EmStepOut(C.Structure):
         ("emitted", C.c_void_p), ("done", C.c_void_p), ("step_latency", C.c_void_p), ("n_draws", C.c_void_p),
         ("reward_seen", C.c_void_p),
     ]
+
+
+class EmsStepOut(C.Structure):
+    """ctypes image of ``ems_step_out`` (scaled topology, compact outputs)."""
+    _fields_ = [("n_pending", C.c_void_p), ("pend_decider", C.c_void_p), ("pend_obs", C.c_void_p), ("reward", C.c_void_p),
+                ("reward_seen", C.c_void_p), ("emitted", C.c_void_p), ("done", C.c_void_p), ("step_latency", C.c_void_p)]
 
 
 class EmMlp3(C.Structure):
@@ -87,6 +93,20 @@ def lib() -> C.CDLL:
     L.em_n_envs.restype = i64
     L.em_set_lanes_per_env.argtypes = [vp, i32]
     L.em_set_workgroup_waves.argtypes = [vp, i32]
+    L.ems_create.argtypes = [C.POINTER(EmConfig), C.c_int32, i64, i32, u64, u64, i64, C.POINTER(vp)]
+    L.ems_destroy.argtypes = [vp]
+    L.ems_reset.argtypes = [vp, i32, u64, C.POINTER(EmsStepOut), vp]
+    L.ems_step.argtypes = [vp, vp, vp, i32, C.POINTER(EmsStepOut), vp]
+    L.ems_episode_metrics.argtypes = [vp, vp, vp]
+    L.ems_set_exploration.argtypes = [vp, i32, i64]
+    L.ems_get_exploration_counter.argtypes = [vp]
+    L.ems_get_exploration_counter.restype = i64
+    L.ems_get_state.argtypes = [vp] + [vp] * 7
+    L.ems_record_bytes.argtypes = [vp]
+    L.ems_record_bytes.restype = i64
+    for name in ("ems_create", "ems_destroy", "ems_reset", "ems_step", "ems_episode_metrics", "ems_set_exploration",
+                 "ems_get_state"):
+        getattr(L, name).restype = C.c_int
     L.em_mlp3_forward.argtypes = [C.POINTER(EmMlp3), vp, i64, i64, vp, vp]
     L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),

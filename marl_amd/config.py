@@ -28,6 +28,17 @@ ENV_CONFIG = {
     "disable_env_exploration": False,
 }
 
+# Scaled topology of BASELINE.json configs[4] / SURVEY.md 8d config 5 (build-defined generalisation, not in the
+# reference): 64 edge servers, 256 decider agents (home server d mod 64), 10x the arrival rate.
+SCALED_ENV_CONFIG = dict(ENV_CONFIG)
+SCALED_ENV_CONFIG.update({
+    "n_nodes": 64,
+    "n_deciders": 256,
+    "node_cpu_capacity": np.linspace(1.0, 3.0, 64) * 1e9,
+    "task_arrival_rate": 100,
+    "task_arrival_rate_range": (50, 150),
+})
+
 
 class EmConfig(C.Structure):
     """ctypes image of ``em_config`` (include/edgemarl.h)."""

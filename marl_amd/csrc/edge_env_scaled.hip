@@ -1,0 +1,698 @@
+// edge_env_scaled.hip - the EdgeSimGym step for the scaled topology: D decider agents
+// over S <= 64 edge servers, one WAVEFRONT per environment, plus its C ABI (ems_*).
+//
+// The step is the reference's (MRRL.PY:188-521) with "agent == server" split into decider d and its home server
+// d mod S (include/edgemarl.h states the generalisation; D == S is the reference bit for bit).  Mapping:
+//   * servers on lanes: load/queue of server s live on lane s (registers + an LDS copy for indexed access);
+//   * the pending list (deciders holding a task, arrival order) on lanes: slot k on lane k, at most 64;
+//   * the arrivals of the step on lanes: arrival j on lane j (more than 64 take a sequential tail).
+// The order-dependent part of the placement loop (MRRL.PY:416,437: agent k sees the load agent k-1 added) is a
+// loop over acting slots in which one lane touches the LDS copy of load[target]; everything else is lane parallel.
+// Outputs are compact (pending list + observation rows), the state record is read and written once per step.
+// All environment arithmetic is float64 in the reference's evaluation order (-ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "edgemarl.h"
+#include "em_common.h"
+#include "em_env_math.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+enum { PCAP = EMS_PENDING_CAP, WAVES_PER_BLOCK = 4, PRE_POIS = 6 };
+enum { SI_STEP = 0, SI_TASKS, SI_VIOL, SI_DONE, SI_PENDING, SI_LOGGED };
+enum { SS_TIME = 0, SS_ELAPSED, SS_SUMLAT, SS_SUMEN };
+
+// state record of one environment (HBM, 16-byte multiple):
+//   f64 load[S] | i32 queue[S] | f64 sim_time, elapsed, sum_lat, sum_energy | i32 step, tasks, viol, completed, pending, logged, 0, 0
+//   | pending list, slot-major arrays: f64 wl[64] | f64 data[64] | f64 deadline[64] | i32 decider[64]
+__host__ __device__ inline int srec_off_queue(int S) { return 8 * S; }
+__host__ __device__ inline int srec_off_scal(int S) { return (12 * S + 7) & ~7; }
+__host__ __device__ inline int srec_off_int(int S) { return srec_off_scal(S) + 32; }
+__host__ __device__ inline int srec_off_pend(int S) { return srec_off_int(S) + 32; }
+__host__ __device__ inline int srec_bytes(int S) { return (srec_off_pend(S) + 28 * PCAP + 15) & ~15; }
+
+struct ScaledParams {
+    int32_t S, D, horizon, rate_mode, explore, rec_bytes, by_slot, step_no;
+    double eps;
+    uint32_t seed_lo, seed_hi, episode, env_offset;
+    int64_t n_envs, lat_cap;
+};
+
+__device__ inline uint64_t lanes_below(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// The per-environment scalar chain of _generate_tasks_and_obs: arrival rate -> time window -> Poisson arrival
+// count (MRRL.PY:220-247,350-351), identical on every lane of the environment's wavefront.
+template <bool RESET>
+__device__ inline void arrival_chain(const ScaledParams& p, const EnvConst* __restrict__ cc, uint32_t eid, uint32_t step_no,
+                                     double t0, double& window, int& n_new)
+{
+    const uint4 b = philox(eid, p.episode, step_no, (P_DT << 24), p.seed_lo, p.seed_hi);
+    const double dt_u = u53(b.x, b.y);
+    const double rate_u = cc->rate_lo + cc->rate_span * u53(b.z, b.w);
+    double pu[PRE_POIS];
+#pragma unroll
+    for (int i = 0; i < PRE_POIS / 2; ++i) {
+        const uint4 q = philox(eid, p.episode, step_no, (P_POIS << 24) | (uint32_t)i, p.seed_lo, p.seed_hi);
+        pu[2 * i] = u53(q.x, q.y);
+        pu[2 * i + 1] = u53(q.z, q.w);
+    }
+    double rate;
+    if (p.rate_mode == 3) rate = cc->rate_lo;                         // degenerate range (MRRL.PY:222-223)
+    else if (p.rate_mode == 1) {
+        const double cyc = cc->cycle, icyc = cc->inv_cycle;           // clamped to >= 1e-6 on the host (MRRL.PY:226)
+        const double phase = qdiv(exact_fmod_pos(t0, cyc, icyc), cyc, icyc);
+        rate = cc->rate_lo + (0.5 + 0.5 * det_sin2pi(phase)) * cc->rate_span;
+    } else if (p.rate_mode == 2) rate = rate_u;
+    else rate = cc->rate_mid;
+    const double rate_c = rate > 1e-6 ? rate : 1e-6;
+    if constexpr (RESET) window = cc->window0;
+    else {
+        const double raw = (1.0 / rate_c) * (-det_log(1.0 - dt_u));
+        const double dt_min = cc->dt_min, dt_max = cc->dt_max;
+        window = raw < dt_min ? dt_min : (raw > dt_max ? dt_max : raw);   // MRRL.PY:247
+    }
+    const double limit = det_exp(-(rate_c * window));
+    double prod = 1.0;
+    bool going = true;
+    n_new = 0;
+#pragma unroll
+    for (int i = 0; i < PRE_POIS; ++i) {     // Knuth's multiplication method on the pre-drawn uniforms
+        prod = prod * pu[i];
+        going = going && prod > limit;
+        n_new += going ? 1 : 0;
+    }
+    if (going) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = PRE_POIS;; ++i) {  // ends at n_new == 4096 at the latest
+            if ((i & 1u) == 0u) q = philox(eid, p.episode, step_no, (P_POIS << 24) | (i >> 1), p.seed_lo, p.seed_hi);
+            const double u = (i & 1u) ? u53(q.z, q.w) : u53(q.x, q.y);
+            prod = prod * u;
+            if (prod > limit && n_new < 4096) ++n_new; else break;
+        }
+    }
+}
+
+__device__ inline void draw_task(const ScaledParams& p, const EnvConst* __restrict__ cc, uint32_t eid, uint32_t step_no, uint32_t j,
+                                 double& wl, double& data, double& offs, int& dec)
+{
+    const uint4 a = philox(eid, p.episode, step_no, (P_TASK_A << 24) | j, p.seed_lo, p.seed_hi);
+    const uint4 b = philox(eid, p.episode, step_no, (P_TASK_B << 24) | j, p.seed_lo, p.seed_hi);
+    wl = cc->wl_lo + cc->wl_span * u53(a.x, a.y);
+    data = cc->data_lo + cc->data_span * u53(a.z, a.w);
+    offs = cc->ddl_lo + cc->ddl_span * u53(b.x, b.y);
+    dec = (int)__umulhi(b.z, (uint32_t)p.D);
+}
+
+// One wavefront per environment; a workgroup is WAVES_PER_BLOCK independent wavefronts (no workgroup barrier).
+template <bool RESET>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const ScaledParams p, unsigned char* __restrict__ state,
+                                                                        const EnvConst* __restrict__ cc,
+                                                                        const int32_t* __restrict__ placement,
+                                                                        const float* __restrict__ resource,
+                                                                        const ems_step_out out, double* __restrict__ lat_log,
+                                                                        int32_t* __restrict__ err_flag)
+{
+    __shared__ double s_load_all[WAVES_PER_BLOCK][64];
+    __shared__ double s_lat_all[WAVES_PER_BLOCK][64];
+    __shared__ double s_en_all[WAVES_PER_BLOCK][64];
+    __shared__ int32_t s_queue_all[WAVES_PER_BLOCK][64];
+    __shared__ float s_ratio_all[WAVES_PER_BLOCK][64];
+    __shared__ int32_t s_pdec_all[WAVES_PER_BLOCK][64];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t env = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (env >= p.n_envs) return;                 // whole wavefronts leave; nothing below synchronises across wavefronts
+    double* s_load = s_load_all[wave];
+    double* s_lat = s_lat_all[wave];
+    double* s_en = s_en_all[wave];
+    int32_t* s_queue = s_queue_all[wave];
+    float* s_ratio = s_ratio_all[wave];
+    int32_t* s_pdec = s_pdec_all[wave];
+
+    const int S = p.S, D = p.D, w = S + 4;
+    const uint32_t eid = p.env_offset + (uint32_t)env;
+    const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
+    unsigned char* rec = state + env * (int64_t)p.rec_bytes;
+    double* g_load = reinterpret_cast<double*>(rec);
+    int32_t* g_queue = reinterpret_cast<int32_t*>(rec + srec_off_queue(S));
+    double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
+    int32_t* g_int = reinterpret_cast<int32_t*>(rec + srec_off_int(S));
+    double* g_pwl = reinterpret_cast<double*>(rec + srec_off_pend(S));
+    double* g_pdata = g_pwl + PCAP;
+    double* g_pddl = g_pdata + PCAP;
+    int32_t* g_pdec = reinterpret_cast<int32_t*>(g_pddl + PCAP);
+    const uint64_t below = lanes_below(lane);
+
+    // ---- global loads first ------------------------------------------------------------------------------------
+    const bool srv = lane < S;
+    const double cap_me = srv ? cc->cap[lane] : 1.0, icap_me = srv ? cc->inv_cap[lane] : 1.0;
+    double load_me = 0.0, t_now = 0.0, el_now = 0.0, acc_lat = 0.0, acc_en = 0.0;
+    int q_me = 0, k_old = 0, tasks_before = 0, n_viol_before = 0, n_done_before = 0;
+    if constexpr (!RESET) {
+        if (srv) { load_me = g_load[lane]; q_me = g_queue[lane]; }
+        t_now = g_scal[SS_TIME]; el_now = g_scal[SS_ELAPSED]; acc_lat = g_scal[SS_SUMLAT]; acc_en = g_scal[SS_SUMEN];
+        tasks_before = g_int[SI_TASKS]; n_viol_before = g_int[SI_VIOL]; n_done_before = g_int[SI_DONE];
+        k_old = g_int[SI_PENDING];
+    }
+    // pending entry of slot `lane` and its action
+    int dec = 0, tgt_in = -1;
+    float res_in = 1.0f;
+    double wl = 1.0, data = 1.0, ddl = 0.0;
+    const bool have = !RESET && lane < k_old;
+    if constexpr (!RESET) {
+        if (have) {
+            dec = g_pdec[lane]; wl = g_pwl[lane]; data = g_pdata[lane]; ddl = g_pddl[lane];
+            const int64_t ai = p.by_slot ? env * PCAP + lane : env * (int64_t)D + dec;
+            tgt_in = placement[ai];
+            res_in = resource[ai];
+        }
+    }
+
+    // ---- random numbers that depend only on (environment, step, lane): the arrivals of this step ------------------
+    double a_wl, a_data, a_offs;
+    int a_dec;
+    draw_task(p, cc, eid, step_no, (uint32_t)lane, a_wl, a_data, a_offs, a_dec);
+
+    double reward = 0.0;
+    if constexpr (!RESET) {
+        // ---- placement phase (MRRL.PY:397-438) ----------------------------------------------------------------
+        s_load[lane] = load_me;
+        s_queue[lane] = q_me;
+        int tgt = tgt_in;
+        const bool acting = have && tgt >= 0 && tgt < S;
+        float res = acting ? res_in : 1.0f;
+        const uint64_t act_bits = __ballot(acting);
+        const int slot = __popcll(act_bits & below);
+        const int k = __popcll(act_bits);
+        if (acting) {
+            if (p.explore) {                 // _maybe_apply_env_exploration, MRRL.PY:258-274
+                const uint4 e1 = philox(eid, p.episode, step_no, (P_EXPL << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
+                const double ex_u = u53(e1.x, e1.y);
+                if (!(ex_u > p.eps)) {
+                    const uint4 e2 = philox(eid, p.episode, step_no, (P_EXPL_RES << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
+                    tgt = (int)__umulhi(e1.z, (uint32_t)S);
+                    res = (float)(0.1 + (1.0 - 0.1) * u53(e2.x, e2.y));
+                }
+            }
+        }
+        const int home = dec % S;
+        double t_trans = 0.0;
+        if (acting && tgt != home) {         // MRRL.PY:409-414
+            const uint4 b = philox(eid, p.episode, step_no, (P_NET << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
+            const double net_bw = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
+            const double net_lat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
+            const double bw = net_bw * 1e6 / 8;
+            t_trans = (data / bw) + net_lat;
+        }
+        const int tl = acting ? tgt : lane;
+        const double cap_t = __shfl(cap_me, tl), icap_t = __shfl(icap_me, tl);
+        const double alloc = cap_t * (double)res;        // MRRL.PY:418 (float64 * float32)
+        const double gcyc = qdiv(alloc, 1e9, 1e-9);
+        const double t_exec = wl / gcyc;                  // MRRL.PY:419
+        const double energy = wl * gcyc;                  // MRRL.PY:423
+        const double inc = t_exec * gcyc;                 // MRRL.PY:437
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ordered chain over acting slots: the queueing delay sees earlier placements (MRRL.PY:416,437)
+        bool viol = false;
+        double t_total = 0.0;
+        for (int s = 0; s < k; ++s) {
+            if (acting && slot == s) {
+                const double l = s_load[tgt];
+                const double t_queue = qdiv(l, cap_t, icap_t);
+                t_total = t_trans + t_queue + t_exec;
+                viol = (t_now + t_total) > ddl;          // MRRL.PY:431
+                s_lat[s] = t_total;
+                s_en[s] = energy;
+                s_load[tgt] = l + inc;
+                s_queue[tgt] += 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int n_viol = __popcll(__ballot(viol));
+
+        // reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466)
+        if (k > 0) {
+            const double sum_lat = np_sum_small(s_lat, k), sum_en = np_sum_small(s_en, k);
+            for (int i = 0; i < k; ++i) { acc_lat += s_lat[i]; acc_en += s_en[i]; }
+            const double kd = (double)k, ik = cc->inv_k[k];
+            const double cost = (cc->w_lat * qdiv(sum_lat, kd, ik)) + (cc->w_en * qdiv(sum_en, kd, ik)) +
+                                (cc->w_viol * (double)n_viol);
+            reward = -cost;
+        }
+        if (out.step_latency) out.step_latency[env * PCAP + lane] = lane < k ? s_lat[lane] : __builtin_nan("");
+        if (lat_log && acting) {
+            const int64_t at = (int64_t)tasks_before + slot;
+            if (at < p.lat_cap) lat_log[env * p.lat_cap + at] = t_total;
+        }
+        tasks_before += k;
+        n_viol_before += n_viol;
+        n_done_before += k - n_viol;
+        load_me = s_load[lane];
+        q_me = s_queue[lane];
+    } else {
+        s_load[lane] = 0.0;
+        s_queue[lane] = 0;
+    }
+
+    // ---- arrivals (MRRL.PY:340-383) ---------------------------------------------------------------------------
+    double window;
+    int n_new;
+    arrival_chain<RESET>(p, cc, eid, step_no, t_now, window, n_new);
+
+    const float ratio_me = srv ? (float)qdiv(load_me, cap_me, icap_me) : 0.0f;   // load/cap BEFORE this step's decay
+    s_ratio[lane] = ratio_me;
+    const bool has = lane < n_new;
+    const double a_deadline = t_now + a_offs;              // MRRL.PY:217
+    const int a_home = a_dec % S;
+    // a later arrival of a decider that already got a task this step only bumps the queue (MRRL.PY:358-359)
+    bool dup = false;
+    const int npar = n_new < 64 ? n_new : 64;
+    for (int i = 0; i + 1 < npar; ++i) {
+        const int di = __shfl(a_dec, i);
+        dup = dup || (lane > i && a_dec == di);
+    }
+    const bool is_new = has && !dup;
+    const uint64_t new_bits = __ballot(is_new);
+    uint64_t dup_bits = __ballot(has && dup);
+    const int rank = __popcll(new_bits & below);
+    int n_pending = __popcll(new_bits);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // queue length the new decider observes (MRRL.PY:311): after the placements, plus the bumps that earlier
+    // arrivals of this step made to its home server (several deciders share a home when D > S)
+    int q_obs = is_new ? s_queue[a_home] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    while (dup_bits != 0ull) {
+        const int i = __ffsll((unsigned long long)dup_bits) - 1;
+        dup_bits &= dup_bits - 1ull;
+        const int hi = __shfl(a_home, i);
+        if (is_new && lane > i && a_home == hi) q_obs += 1;
+        if (lane == hi) q_me += 1;                          // lane hi < S owns server hi
+    }
+    if (is_new) s_pdec[rank] = a_dec;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // observation rows of the new pending deciders (_get_obs, MRRL.PY:307-324), compact, in arrival order
+    {
+        uint64_t nb = new_bits;
+        int r = 0;
+        while (nb != 0ull) {
+            const int j = __ffsll((unsigned long long)nb) - 1;
+            nb &= nb - 1ull;
+            const int h = __shfl(a_home, j);
+            const double rem_d = __shfl(a_deadline, j) - t_now;
+            const float c1 = (float)__shfl(q_obs, j), c2 = (float)__shfl(a_data, j), c3 = (float)__shfl(a_wl, j);
+            const float c4 = (float)(rem_d > 0 ? rem_d : 0.0);
+            float* row = out.pend_obs + (env * PCAP + r) * (int64_t)w;
+            for (int c = lane; c < w; c += 64) {
+                float v;
+                if (c == 0) v = s_ratio[h];
+                else if (c == 1) v = c1;
+                else if (c == 2) v = c2;
+                else if (c == 3) v = c3;
+                else if (c == 4) v = c4;
+                else { const int i = c - 5; v = s_ratio[i < h ? i : i + 1]; }
+                row[c] = v;
+            }
+            ++r;
+        }
+    }
+    if (is_new) {                                           // MRRL.PY:361: the decider's pending task
+        g_pwl[rank] = a_wl; g_pdata[rank] = a_data; g_pddl[rank] = a_deadline; g_pdec[rank] = a_dec;
+        out.pend_decider[env * PCAP + rank] = a_dec;
+    }
+
+    if (n_new > 64) {
+        // rare tail: arrivals beyond one per lane, one at a time in arrival order.  s_queue holds the queue lengths
+        // of the moment (placements + bumps so far); lane r < n_pending holds pending decider r for the busy test.
+        s_queue[lane] = q_me;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 64; j < n_new; ++j) {
+            double twl, tdata, toffs;
+            int tdec;
+            draw_task(p, cc, eid, step_no, (uint32_t)j, twl, tdata, toffs, tdec);
+            const int th = tdec % S;
+            const bool busy = __ballot(lane < n_pending && lane < PCAP && s_pdec[lane] == tdec) != 0ull;
+            const int q_now = s_queue[th];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (busy) {
+                if (lane == 0) s_queue[th] = q_now + 1;
+            } else if (n_pending >= PCAP) {
+                if (lane == 0) atomicOr(err_flag, 16);      // more than 64 deciders hold a task: not representable
+            } else {
+                const double deadline = t_now + toffs, rem_d = deadline - t_now;
+                float* row = out.pend_obs + (env * PCAP + n_pending) * (int64_t)w;
+                for (int c = lane; c < w; c += 64) {
+                    float v;
+                    if (c == 0) v = s_ratio[th];
+                    else if (c == 1) v = (float)q_now;
+                    else if (c == 2) v = (float)tdata;
+                    else if (c == 3) v = (float)twl;
+                    else if (c == 4) v = (float)(rem_d > 0 ? rem_d : 0.0);
+                    else { const int i = c - 5; v = s_ratio[i < th ? i : i + 1]; }
+                    row[c] = v;
+                }
+                if (lane == 0) {
+                    g_pwl[n_pending] = twl; g_pdata[n_pending] = tdata; g_pddl[n_pending] = deadline; g_pdec[n_pending] = tdec;
+                    out.pend_decider[env * PCAP + n_pending] = tdec;
+                    s_pdec[n_pending] = tdec;
+                }
+                n_pending += 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        q_me = s_queue[lane];
+    }
+
+    // ---- decay, clock, outputs (MRRL.PY:364-375,444-459) ---------------------------------------------------------
+    if constexpr (!RESET) {
+        double l = load_me - cap_me * window;
+        if (!(l > 0)) l = 0.0;
+        load_me = l;
+        q_me = q_me - 1 > 0 ? q_me - 1 : 0;
+    }
+    if (srv) { g_load[lane] = load_me; g_queue[lane] = q_me; }
+    if (lane == 0) {
+        if constexpr (!RESET) {
+            g_scal[SS_TIME] = t_now + window;
+            g_scal[SS_ELAPSED] = el_now + window;
+            g_scal[SS_SUMLAT] = acc_lat;
+            g_scal[SS_SUMEN] = acc_en;
+            g_int[SI_STEP] = (int32_t)step_no;
+            g_int[SI_TASKS] = tasks_before;
+            g_int[SI_VIOL] = n_viol_before;
+            g_int[SI_DONE] = n_done_before;
+            if (lat_log) g_int[SI_LOGGED] = (int32_t)((int64_t)tasks_before < p.lat_cap ? (int64_t)tasks_before : p.lat_cap);
+            if (out.reward) out.reward[env] = reward;
+            if (out.emitted) out.emitted[env] = n_pending > 0;
+            if (out.reward_seen) out.reward_seen[env] = n_pending > 0 ? reward : 0.0;
+            if (out.done) out.done[env] = (int32_t)step_no >= p.horizon;
+        } else {
+            g_scal[SS_TIME] = 0.0; g_scal[SS_ELAPSED] = 0.0; g_scal[SS_SUMLAT] = 0.0; g_scal[SS_SUMEN] = 0.0;
+            g_int[SI_STEP] = 0; g_int[SI_TASKS] = 0; g_int[SI_VIOL] = 0; g_int[SI_DONE] = 0; g_int[SI_LOGGED] = 0;
+        }
+        g_int[SI_PENDING] = n_pending;
+        out.n_pending[env] = n_pending;
+    }
+}
+
+// Episode metrics (MRRL.PY:470-504); p99 from the latency log when present.  One workgroup per environment.
+__global__ __launch_bounds__(256) void scaled_metrics_kernel(const ScaledParams p, const unsigned char* __restrict__ state,
+                                                             const EnvConst* __restrict__ cc, const double* __restrict__ lat_log,
+                                                             double* __restrict__ scratch, double* __restrict__ out6)
+{
+    const int64_t env = blockIdx.x;
+    const int S = p.S;
+    const unsigned char* rec = state + env * (int64_t)p.rec_bytes;
+    const double* scal = reinterpret_cast<const double*>(rec + srec_off_scal(S));
+    const int32_t* ri = reinterpret_cast<const int32_t*>(rec + srec_off_int(S));
+    const int tasks = ri[SI_TASKS];
+    const int logged = lat_log ? ri[SI_LOGGED] : 0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* v = reinterpret_cast<double*>(smem);
+    double p99 = __builtin_nan("");
+    if (tasks == 0) p99 = 0.0;
+    else if (lat_log && logged == tasks) {
+        int m = 1;
+        while (m < logged) m <<= 1;
+        double* buf = (m * 8 <= 128 * 1024) ? v : scratch + env * p.lat_cap * 2;   // large logs sort in HBM scratch
+        for (int i = threadIdx.x; i < m; i += blockDim.x)
+            buf[i] = i < logged ? lat_log[env * p.lat_cap + i] * 1000 : __builtin_inf();
+        __syncthreads();
+        for (int size = 2; size <= m; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < (m >> 1); i += blockDim.x) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const double a = buf[lo], b = buf[hi];
+                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) {
+            const double vi = (double)(logged - 1) * (99.0 / 100.0);   // numpy 'linear' method
+            const double fl = floor(vi);
+            int lo = (int)fl, hi = lo + 1;
+            if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
+            if (hi > logged - 1) hi = logged - 1;
+            const double a = buf[lo], b = buf[hi], t = vi - fl, d = b - a;
+            p99 = (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
+        }
+    }
+    if (threadIdx.x == 0) {
+        double* o = out6 + env * 6;
+        const double cnt = (double)(tasks ? tasks : 1);
+        o[0] = tasks ? scal[SS_SUMLAT] * 1000 / (double)tasks : 0.0;
+        o[1] = p99;
+        o[2] = tasks ? scal[SS_SUMEN] / (double)tasks : __builtin_nan("");
+        o[3] = (double)ri[SI_VIOL] / cnt;
+        const double el = scal[SS_ELAPSED];
+        o[4] = (double)ri[SI_DONE] / (el > 1e-6 ? el : 1e-6);
+        // Jain index over per-server mean cpu usage; usage sample of a step = cap*dt/(cap+1e-9) (MRRL.PY:379-381)
+        const double samples = (double)(ri[SI_STEP] + 1);
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < S; ++i) {
+            const double m_i = (cc->cap[i] * el / (cc->cap[i] + 1e-9)) / samples;
+            s1 += m_i;
+            s2 += m_i * m_i;
+        }
+        o[5] = (s1 * s1) / ((double)S * s2 + 1e-9);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct ems_handle {
+    em_config cfg;
+    int32_t n_deciders = 0;
+    int64_t n_envs = 0;
+    int device = 0;
+    uint64_t seed = 0, env_offset = 0;
+    uint32_t episode = 0;
+    int64_t explore_counter = 0;
+    int explore_off = 0;
+    int64_t lat_cap = 0;
+    int32_t step = 0;
+    unsigned char* d_state = nullptr;
+    EnvConst* d_const = nullptr;
+    double* d_lat_log = nullptr;
+    double* d_sort_scratch = nullptr;
+    int32_t* d_err = nullptr;
+    bool was_reset = false;
+};
+
+namespace {
+
+ScaledParams make_sparams(const ems_handle* h)
+{
+    const em_config& c = h->cfg;
+    ScaledParams p;
+    std::memset(&p, 0, sizeof p);
+    p.S = c.n_nodes;
+    p.D = h->n_deciders;
+    p.horizon = c.episode_length;
+    p.rate_mode = c.arrival_rate_lo == c.arrival_rate_hi ? 3 : c.arrival_mode;
+    p.explore = h->explore_off ? 0 : 1;
+    p.rec_bytes = srec_bytes(p.S);
+    double eps = 0.0;                                   // _get_current_epsilon, MRRL.PY:249-256
+    if (!h->explore_off) {
+        double frac = (double)h->explore_counter / (double)(c.decay_steps > 1 ? c.decay_steps : 1);
+        if (frac > 1.0) frac = 1.0;
+        eps = c.initial_epsilon - (c.initial_epsilon - c.final_epsilon) * frac;
+    }
+    p.eps = eps;
+    p.seed_lo = (uint32_t)h->seed; p.seed_hi = (uint32_t)(h->seed >> 32);
+    p.episode = h->episode;
+    p.step_no = h->step + 1;
+    p.env_offset = (uint32_t)h->env_offset;
+    p.n_envs = h->n_envs;
+    p.lat_cap = h->lat_cap;
+    return p;
+}
+
+int check_sout(const ems_step_out* out)
+{
+    if (!out || !out->n_pending || !out->pend_decider || !out->pend_obs)
+        return em::fail(EM_ERR_INVALID, "n_pending, pend_decider and pend_obs outputs are required");
+    return EM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ems_create(const em_config* cfg, int32_t n_deciders, int64_t n_envs, int device_id, uint64_t seed, uint64_t env_offset,
+               int64_t latency_log_capacity, ems_handle** out)
+{
+    if (!cfg || !out) return em::fail(EM_ERR_INVALID, "ems_create: null argument");
+    if (cfg->n_nodes < 1 || cfg->n_nodes > EM_MAX_NODES) return em::fail(EM_ERR_INVALID, "n_nodes must be 1..%d", EM_MAX_NODES);
+    if (n_deciders < 1 || n_deciders > EMS_MAX_DECIDERS) return em::fail(EM_ERR_INVALID, "n_deciders must be 1..%d", EMS_MAX_DECIDERS);
+    if (n_envs < 1 || n_envs > (1ll << 31)) return em::fail(EM_ERR_INVALID, "n_envs out of range");
+    if (cfg->episode_length < 1) return em::fail(EM_ERR_INVALID, "episode_length must be positive");
+    if (!(cfg->min_time_step > 0) || !(cfg->max_time_step >= cfg->min_time_step))
+        return em::fail(EM_ERR_INVALID, "need 0 < min_time_step <= max_time_step");
+    if (latency_log_capacity < 0) return em::fail(EM_ERR_INVALID, "latency_log_capacity must be >= 0");
+    for (int i = 0; i < cfg->n_nodes; ++i)
+        if (!(cfg->node_cpu_capacity[i] > 0)) return em::fail(EM_ERR_INVALID, "node_cpu_capacity[%d] must be positive", i);
+    EM_HIP(hipSetDevice(device_id));
+    ems_handle* h = new (std::nothrow) ems_handle();
+    if (!h) return em::fail(EM_ERR_INVALID, "out of host memory");
+    h->cfg = *cfg;
+    h->n_deciders = n_deciders;
+    h->n_envs = n_envs;
+    h->device = device_id;
+    h->seed = seed;
+    h->env_offset = env_offset;
+    h->explore_off = cfg->disable_env_exploration;
+    h->lat_cap = latency_log_capacity;
+    const size_t sbytes = (size_t)n_envs * srec_bytes(cfg->n_nodes);
+    hipError_t e = hipMalloc(&h->d_state, sbytes);
+    if (e == hipSuccess) e = hipMemset(h->d_state, 0, sbytes);
+    if (e == hipSuccess) e = hipMalloc(&h->d_const, sizeof(EnvConst));
+    if (e == hipSuccess) {
+        const EnvConst k = make_const(*cfg);
+        e = hipMemcpy(h->d_const, &k, sizeof k, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc(&h->d_err, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(h->d_err, 0, sizeof(int32_t));
+    if (e == hipSuccess && h->lat_cap > 0) {
+        e = hipMalloc(&h->d_lat_log, sizeof(double) * (size_t)n_envs * (size_t)h->lat_cap);
+        if (e == hipSuccess && h->lat_cap * 8 > 64 * 1024)
+            e = hipMalloc(&h->d_sort_scratch, sizeof(double) * 2 * (size_t)n_envs * (size_t)h->lat_cap);
+    }
+    if (e != hipSuccess) {
+        ems_destroy(h);
+        return em::hip_fail(e, "ems_create allocation");
+    }
+    *out = h;
+    return EM_OK;
+}
+
+int ems_destroy(ems_handle* h)
+{
+    if (!h) return EM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_const) (void)hipFree(h->d_const);
+    if (h->d_lat_log) (void)hipFree(h->d_lat_log);
+    if (h->d_sort_scratch) (void)hipFree(h->d_sort_scratch);
+    if (h->d_err) (void)hipFree(h->d_err);
+    delete h;
+    return EM_OK;
+}
+
+int ems_reset(ems_handle* h, int has_seed, uint64_t seed, const ems_step_out* out, void* stream)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "ems_reset: null handle");
+    const int rc = check_sout(out);
+    if (rc) return rc;
+    if (has_seed) { h->seed = seed; h->episode = 0; }
+    h->episode += 1;
+    h->was_reset = true;
+    h->step = 0;
+    const ScaledParams p = make_sparams(h);
+    const dim3 grid((unsigned)((h->n_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    hipLaunchKernelGGL((scaled_env_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
+                       nullptr, *out, h->d_lat_log, h->d_err);
+    return em::hip_check(hipGetLastError(), "scaled_env_kernel<reset> launch");
+}
+
+int ems_step(ems_handle* h, const int32_t* placement, const float* resource, int actions_by_slot, const ems_step_out* out,
+             void* stream)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "ems_step: null handle");
+    if (!h->was_reset) return em::fail(EM_ERR_STATE, "ems_step before ems_reset");
+    if (!placement || !resource) return em::fail(EM_ERR_INVALID, "ems_step: placement/resource are required");
+    const int rc = check_sout(out);
+    if (rc) return rc;
+    ScaledParams p = make_sparams(h);
+    p.by_slot = actions_by_slot ? 1 : 0;
+    const dim3 grid((unsigned)((h->n_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    hipLaunchKernelGGL((scaled_env_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
+                       resource, *out, h->d_lat_log, h->d_err);
+    const int lrc = em::hip_check(hipGetLastError(), "scaled_env_kernel<step> launch");
+    if (lrc) return lrc;
+    h->step += 1;
+    if (!h->explore_off) h->explore_counter += 1;   // MRRL.PY:467-468
+    return EM_OK;
+}
+
+int ems_episode_metrics(ems_handle* h, double* out6, void* stream)
+{
+    if (!h || !out6) return em::fail(EM_ERR_INVALID, "ems_episode_metrics: null argument");
+    const ScaledParams p = make_sparams(h);
+    int64_t m = 1;
+    while (m < h->lat_cap) m <<= 1;
+    size_t lds = h->d_lat_log ? (size_t)m * 8 : 16;
+    if (lds > 128 * 1024) lds = 16;
+    if (lds > 64 * 1024)
+        EM_HIP(hipFuncSetAttribute((const void*)scaled_metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(scaled_metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, (hipStream_t)stream, p, h->d_state,
+                       h->d_const, h->d_lat_log, h->d_sort_scratch, out6);
+    return em::hip_check(hipGetLastError(), "scaled_metrics_kernel launch");
+}
+
+int ems_set_exploration(ems_handle* h, int disable_env_exploration, int64_t global_step_counter)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "null handle");
+    if (global_step_counter < 0) return em::fail(EM_ERR_INVALID, "counter must be >= 0");
+    h->explore_off = disable_env_exploration ? 1 : 0;
+    h->explore_counter = global_step_counter;
+    return EM_OK;
+}
+
+int64_t ems_get_exploration_counter(const ems_handle* h) { return h ? h->explore_counter : -1; }
+int64_t ems_record_bytes(const ems_handle* h) { return h ? srec_bytes(h->cfg.n_nodes) : -1; }
+
+int ems_get_state(ems_handle* h, double* load, double* queue, double* sim_time, double* elapsed, int32_t* step,
+                  int64_t* counts, void* stream)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "null handle");
+    const int S = h->cfg.n_nodes, rb = srec_bytes(S);
+    std::vector<unsigned char> host((size_t)h->n_envs * rb);
+    EM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    EM_HIP(hipMemcpy(host.data(), h->d_state, host.size(), hipMemcpyDeviceToHost));
+    int32_t err = 0;
+    EM_HIP(hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) return em::fail(EM_ERR_INVALID, "device flagged an unrepresentable state (flags %d: 16 = more than %d pending deciders)", err, PCAP);
+    for (int64_t b = 0; b < h->n_envs; ++b) {
+        const unsigned char* rec = host.data() + b * rb;
+        const double* ld = reinterpret_cast<const double*>(rec);
+        const int32_t* q = reinterpret_cast<const int32_t*>(rec + srec_off_queue(S));
+        const double* sc = reinterpret_cast<const double*>(rec + srec_off_scal(S));
+        const int32_t* ri = reinterpret_cast<const int32_t*>(rec + srec_off_int(S));
+        for (int i = 0; i < S; ++i) {
+            if (load) load[b * S + i] = ld[i];
+            if (queue) queue[b * S + i] = (double)q[i];
+        }
+        if (sim_time) sim_time[b] = sc[SS_TIME];
+        if (elapsed) elapsed[b] = sc[SS_ELAPSED];
+        if (step) step[b] = ri[SI_STEP];
+        if (counts) { counts[3 * b] = ri[SI_TASKS]; counts[3 * b + 1] = ri[SI_VIOL]; counts[3 * b + 2] = ri[SI_DONE]; }
+    }
+    return EM_OK;
+}
+
+}  // extern "C"

@@ -296,6 +296,9 @@ class EdgeEnvOracle:
     def __init__(self, config=None, draws=None, tape_out=None):
         cfg = default_config() if config is None else config
         self.n = int(cfg["n_nodes"])
+        # Scaled topology (build-defined, NOT in the reference): D decider agents over
+        # S = n_nodes servers, home server of decider d = d mod S.  D == S (the default) is the reference.
+        self.D = int(cfg.get("n_deciders", self.n))
         self.rate_fixed = cfg.get("task_arrival_rate", 10)
         self.rate_range = cfg.get("task_arrival_rate_range", (self.rate_fixed, self.rate_fixed))
         self.rate_mode = cfg.get("task_arrival_mode", "cyclic")
@@ -376,16 +379,21 @@ class EdgeEnvOracle:
             self.tape_out["n_draws"][self._tape_step] += k
 
     # -- MRRL.PY:307-324 -------------------------------------------------------------------------
+    def home(self, d):
+        """Server a decider is attached to (its "local" placement): the identity in the reference."""
+        return d % self.n
+
     def _obs_row(self, d, wl, data, deadline, t):
         ratio = self.load / self.cap
-        head = [ratio[d], self.queue[d], data, wl, max(0, deadline - t)]
-        rest = [ratio[j] for j in range(self.n) if j != d]
+        h = self.home(d)
+        head = [ratio[h], self.queue[h], data, wl, max(0, deadline - t)]
+        rest = [ratio[j] for j in range(self.n) if j != h]
         return np.array(head + rest, dtype=np.float32)
 
     # -- MRRL.PY:340-383 -------------------------------------------------------------------------
     def _arrivals(self, t, advance):
         self.pending = {}
-        obs = np.zeros((self.n, self.n + 4), np.float32)
+        obs = np.zeros((self.D, self.n + 4), np.float32)
         rate = self._rate(t)
         if advance:
             scale = 1.0 / max(rate, 1e-6)
@@ -400,7 +408,7 @@ class EdgeEnvOracle:
         self._rec("n_arr", n_new)
         self._count()
         for j in range(n_new):
-            wl, data, off, dec = self.draws.task(j, self.wl_rng, self.data_rng, self.ddl_rng, self.n)
+            wl, data, off, dec = self.draws.task(j, self.wl_rng, self.data_rng, self.ddl_rng, self.D)
             if self.tape_out is not None:
                 if j >= self.tape_out["task_wl"].shape[1]:
                     raise AssertionError("tape arrival slots exhausted")
@@ -411,7 +419,7 @@ class EdgeEnvOracle:
             self._count(4)
             deadline = t + off
             if dec in self.pending:
-                self.queue[dec] += 1
+                self.queue[self.home(dec)] += 1
             else:
                 self.pending[dec] = (wl, data, deadline)
                 obs[dec] = self._obs_row(dec, wl, data, deadline, t)
@@ -464,7 +472,7 @@ class EdgeEnvOracle:
                     self._rec("explore_res", r64, k)
                     self._count(2)
                     res = np.array([r64], dtype=np.float32)[0]
-            if target == agent:
+            if target == self.home(agent):
                 t_trans = 0.0
             else:
                 bw_u, lat = self.draws.net(k, agent, self.bw_rng, self.lat_rng)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "edgemarl.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(em_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ems?_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_entry_points():
