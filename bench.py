@@ -259,6 +259,71 @@ def fused_leg(device, rank, world, B, k_steps=250, launches=8):
             "outputs": "reward/done history [k][B] + last observation", "note": "state records stay in LDS between steps"}
 
 
+def scaled_leg(device, rank, world, B=65536, steps=300):
+    """configs[4] environment: 64 edge servers x 256 decider agents, 10x arrival rate (ems_step, one wavefront per
+    environment, compact outputs).  Random per-slot actions resident in HBM; reported beside the headline."""
+    import torch.distributed as dist
+    from marl_amd.config import SCALED_ENV_CONFIG
+    from marl_amd.env_scaled import PENDING_CAP, ScaledEdgeSimGym
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["disable_env_exploration"] = True
+    env = ScaledEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B)
+    S, D, T = env.n_nodes, env.n_deciders, env.episode_len
+    gen = torch.Generator(device=device).manual_seed(99 + rank)
+    pool = [(torch.randint(0, S, (B, PENDING_CAP), device=device, generator=gen, dtype=torch.int32),
+             (torch.rand((B, PENDING_CAP), device=device, generator=gen) * 0.9 + 0.1).contiguous()) for _ in range(8)]
+    ptrs = [(p.data_ptr(), r.data_ptr()) for p, r in pool]
+    L, h, out = env._L, env._h, C.byref(env._out)
+    stream = torch.cuda.current_stream(device)
+    sptr = stream.cuda_stream
+    ksum = torch.zeros((), dtype=torch.int64, device=device)
+
+    def run(k, counter, count_pending=False):
+        for _ in range(k):
+            if counter[0] % T == 0:
+                env.reset()
+            pp, rr = ptrs[counter[0] % 8]
+            if L.ems_step(h, pp, rr, 1, out, sptr):
+                raise RuntimeError(L.em_last_error().decode())
+            if count_pending:
+                ksum.add_(env.n_pending.sum())
+            counter[0] += 1
+
+    counter = [0]
+    run(40, counter, True)
+    kbar = ksum.item() / (40.0 * B)              # mean deciders holding a task per step
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(steps, counter)
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.close()
+    # algorithmic bytes per env-step (DESIGN.md 4.4): fixed record part read+written, pending entries read and written,
+    # actions of the acting slots, compact outputs (observation row + decider id per pending decider, 22 B of scalars)
+    per_step = 2 * (12 * S + 64) + 28 * 2 * kbar + 8 * kbar + kbar * (4 * (S + 4) + 4) + 22
+    ach = per_step * B / (dev_ms * 1e-3 / steps) / 1e9
+    return {"workload": "scaled topology: 64 servers x 256 deciders, 10x arrival rate, random actions, step-only",
+            "entry_point": "ems_step", "n_envs_per_gpu": B, "steps": steps, "env_steps_per_s": world * B * steps / elapsed,
+            "value": world * B * D * steps / elapsed, "unit": "agent-steps/s", "mean_pending_per_step": kbar,
+            "avg_launch_us": dev_ms * 1e3 / steps,
+            "roofline": {"bound": "hbm", "kernel": "scaled_env_kernel<step>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
+
+
 def traffic_for(B):
     """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -301,8 +366,10 @@ def main():
         e2, d2, _, _, _ = time_env_steps(device, rank, world, 65536, k, max(20, args.warmup // 4))
         scale = (65536, k, e2, d2)
     fused = None
+    scaled = None
     if not args.no_scale_point:
         fused = fused_leg(device, rank, world, B)
+        scaled = scaled_leg(device, rank, world)
     mappo = None
     if not args.no_mappo:
         mappo = mappo_leg(device, rank, world, args.mappo_envs)
@@ -347,6 +414,8 @@ def main():
                                                 "bytes_per_launch": s_bytes}}
         if fused is not None:
             line["fused_steps"] = fused
+        if scaled is not None:
+            line["scaled_topology"] = scaled
         if mappo is not None:
             line["mappo"] = mappo
         print(json.dumps(line), flush=True)

@@ -9,6 +9,11 @@
 // The order-dependent part of the placement loop (MRRL.PY:416,437: agent k sees the load agent k-1 added) is a
 // loop over acting slots in which one lane touches the LDS copy of load[target]; everything else is lane parallel.
 // Outputs are compact (pending list + observation rows), the state record is read and written once per step.
+// Two things keep the wavefront's instruction count down (the step is VALU-issue bound, not HBM bound, when every
+// lane of a wavefront repeats per-environment scalar work): (1) the per-environment scalar chain of
+// _generate_tasks_and_obs (rate -> window -> Poisson count) depends on the clock only, never on the actions, so
+// scaled_chain_kernel evaluates it one environment per LANE for CHAIN_ROWS steps ahead; (2) all Philox blocks a step
+// needs (arrivals, network draws, exploration) are evaluated in ONE pass with a lane-dependent counter.
 // All environment arithmetic is float64 in the reference's evaluation order (-ffp-contract=off).
 #include <hip/hip_runtime.h>
 
@@ -27,7 +32,7 @@
 
 namespace {
 
-enum { PCAP = EMS_PENDING_CAP, WAVES_PER_BLOCK = 4, PRE_POIS = 6 };
+enum { PCAP = EMS_PENDING_CAP, WAVES_PER_BLOCK = 4, PRE_POIS = 6, CHAIN_ROWS = 16 };
 enum { SI_STEP = 0, SI_TASKS, SI_VIOL, SI_DONE, SI_PENDING, SI_LOGGED };
 enum { SS_TIME = 0, SS_ELAPSED, SS_SUMLAT, SS_SUMEN };
 
@@ -112,12 +117,51 @@ __device__ inline void draw_task(const ScaledParams& p, const EnvConst* __restri
     dec = (int)__umulhi(b.z, (uint32_t)p.D);
 }
 
+__device__ inline int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ inline double rl_d(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The scalar chain for `rows` consecutive steps, one environment per lane.  Row r holds step first_step + r; step 0 is
+// the reset (fixed window, clock does not advance: MRRL.PY:209,345-348).  `clock` carries each environment's
+// sim_time between launches: t(k+1) = t(k) + window(k) is the very sum the step kernel stores (MRRL.PY:444-447).
+__global__ __launch_bounds__(256) void scaled_chain_kernel(const ScaledParams p, const EnvConst* __restrict__ cc,
+                                                           double* __restrict__ clock, double* __restrict__ win_out,
+                                                           int32_t* __restrict__ n_out, int first_step, int rows)
+{
+    const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (env >= p.n_envs) return;
+    const uint32_t eid = p.env_offset + (uint32_t)env;
+    double t = first_step == 0 ? 0.0 : clock[env];
+    for (int r = 0; r < rows; ++r) {
+        const uint32_t step_no = (uint32_t)(first_step + r);
+        double window;
+        int n_new;
+        if (step_no == 0u) arrival_chain<true>(p, cc, eid, step_no, t, window, n_new);
+        else {
+            arrival_chain<false>(p, cc, eid, step_no, t, window, n_new);
+            t = t + window;
+        }
+        win_out[(int64_t)r * p.n_envs + env] = window;
+        n_out[(int64_t)r * p.n_envs + env] = n_new;
+    }
+    clock[env] = t;
+}
+
 // One wavefront per environment; a workgroup is WAVES_PER_BLOCK independent wavefronts (no workgroup barrier).
+// chain_win / chain_n: this step's row of the scalar chain (scaled_chain_kernel).
 template <bool RESET>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const ScaledParams p, unsigned char* __restrict__ state,
                                                                         const EnvConst* __restrict__ cc,
                                                                         const int32_t* __restrict__ placement,
                                                                         const float* __restrict__ resource,
+                                                                        const double* __restrict__ chain_win,
+                                                                        const int32_t* __restrict__ chain_n,
                                                                         const ems_step_out out, double* __restrict__ lat_log,
                                                                         int32_t* __restrict__ err_flag)
 {
@@ -177,10 +221,47 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
         }
     }
 
-    // ---- random numbers that depend only on (environment, step, lane): the arrivals of this step ------------------
-    double a_wl, a_data, a_offs;
-    int a_dec;
-    draw_task(p, cc, eid, step_no, (uint32_t)lane, a_wl, a_data, a_offs, a_dec);
+    const double window = chain_win[env];
+    const int n_new = chain_n[env];
+
+    // ---- every Philox block of the step in one pass per 8 arrivals / 16 pending slots ---------------------------
+    // producer lanes 0-7: P_TASK_A of arrival 8q+i, 8-15: P_TASK_B, 16-31: P_NET of the decider in slot 16q+i,
+    // 32-47: P_EXPL, 48-63: P_EXPL_RES; the consumers (arrival j on lane j, slot k on lane k) fetch by shuffle.  The
+    // stream is counter addressed, so drawing a number the reference would not have drawn changes nothing.
+    double a_wl = 0.0, a_data = 0.0, a_offs = 0.0, net_bw = 0.0, net_lat = 0.0, ex_u = 2.0, ex_res = 0.0;
+    int a_dec = 0, ex_tgt = 0;
+    {
+        const int n_par = n_new < 64 ? n_new : 64;
+        const int pa = (n_par + 7) >> 3, ps = (k_old + 15) >> 4;
+        const int n_pass = pa > ps ? pa : ps;
+        for (int q = 0; q < n_pass; ++q) {
+            const int d_slot = __shfl(dec, (16 * q + (lane & 15)) & 63);
+            uint32_t word;
+            if (lane < 8) word = (P_TASK_A << 24) | (uint32_t)(8 * q + lane);
+            else if (lane < 16) word = (P_TASK_B << 24) | (uint32_t)(8 * q + lane - 8);
+            else word = ((lane < 32 ? P_NET : (lane < 48 ? P_EXPL : P_EXPL_RES)) << 24) | (uint32_t)d_slot;
+            const uint4 b = philox(eid, p.episode, step_no, word, p.seed_lo, p.seed_hi);
+            const double d0 = u53(b.x, b.y), d1 = u53(b.z, b.w);
+            const int sa = lane & 7, ss = lane & 15;
+            const double ta0 = __shfl(d0, sa), ta1 = __shfl(d1, sa), tb0 = __shfl(d0, 8 + sa);
+            const uint32_t tbz = (uint32_t)__shfl((int)b.z, 8 + sa);
+            const double nn0 = __shfl(d0, 16 + ss), nn1 = __shfl(d1, 16 + ss), ee0 = __shfl(d0, 32 + ss), rr0 = __shfl(d0, 48 + ss);
+            const uint32_t eez = (uint32_t)__shfl((int)b.z, 32 + ss);
+            if ((lane >> 3) == q) {
+                a_wl = cc->wl_lo + cc->wl_span * ta0;
+                a_data = cc->data_lo + cc->data_span * ta1;
+                a_offs = cc->ddl_lo + cc->ddl_span * tb0;
+                a_dec = (int)__umulhi(tbz, (uint32_t)D);
+            }
+            if ((lane >> 4) == q) {
+                net_bw = cc->bw_lo + cc->bw_span * nn0;
+                net_lat = cc->lat_lo + cc->lat_span * nn1;
+                ex_u = ee0;
+                ex_tgt = (int)__umulhi(eez, (uint32_t)S);
+                ex_res = 0.1 + (1.0 - 0.1) * rr0;
+            }
+        }
+    }
 
     double reward = 0.0;
     if constexpr (!RESET) {
@@ -194,22 +275,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
         const int slot = __popcll(act_bits & below);
         const int k = __popcll(act_bits);
         if (acting) {
-            if (p.explore) {                 // _maybe_apply_env_exploration, MRRL.PY:258-274
-                const uint4 e1 = philox(eid, p.episode, step_no, (P_EXPL << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
-                const double ex_u = u53(e1.x, e1.y);
-                if (!(ex_u > p.eps)) {
-                    const uint4 e2 = philox(eid, p.episode, step_no, (P_EXPL_RES << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
-                    tgt = (int)__umulhi(e1.z, (uint32_t)S);
-                    res = (float)(0.1 + (1.0 - 0.1) * u53(e2.x, e2.y));
-                }
+            if (p.explore && !(ex_u > p.eps)) {   // _maybe_apply_env_exploration, MRRL.PY:258-274
+                tgt = ex_tgt;
+                res = (float)ex_res;
             }
         }
         const int home = dec % S;
         double t_trans = 0.0;
         if (acting && tgt != home) {         // MRRL.PY:409-414
-            const uint4 b = philox(eid, p.episode, step_no, (P_NET << 24) | (uint32_t)dec, p.seed_lo, p.seed_hi);
-            const double net_bw = cc->bw_lo + cc->bw_span * u53(b.x, b.y);
-            const double net_lat = cc->lat_lo + cc->lat_span * u53(b.z, b.w);
             const double bw = net_bw * 1e6 / 8;
             t_trans = (data / bw) + net_lat;
         }
@@ -267,10 +340,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
     }
 
     // ---- arrivals (MRRL.PY:340-383) ---------------------------------------------------------------------------
-    double window;
-    int n_new;
-    arrival_chain<RESET>(p, cc, eid, step_no, t_now, window, n_new);
-
     const float ratio_me = srv ? (float)qdiv(load_me, cap_me, icap_me) : 0.0f;   // load/cap BEFORE this step's decay
     s_ratio[lane] = ratio_me;
     const bool has = lane < n_new;
@@ -280,7 +349,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
     bool dup = false;
     const int npar = n_new < 64 ? n_new : 64;
     for (int i = 0; i + 1 < npar; ++i) {
-        const int di = __shfl(a_dec, i);
+        const int di = rl_i(a_dec, i);
         dup = dup || (lane > i && a_dec == di);
     }
     const bool is_new = has && !dup;
@@ -298,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
     while (dup_bits != 0ull) {
         const int i = __ffsll((unsigned long long)dup_bits) - 1;
         dup_bits &= dup_bits - 1ull;
-        const int hi = __shfl(a_home, i);
+        const int hi = rl_i(a_home, i);
         if (is_new && lane > i && a_home == hi) q_obs += 1;
         if (lane == hi) q_me += 1;                          // lane hi < S owns server hi
     }
@@ -307,16 +376,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void scaled_env_kernel(const 
     __builtin_amdgcn_wave_barrier();
 
     // observation rows of the new pending deciders (_get_obs, MRRL.PY:307-324), compact, in arrival order
+    const double a_rem = a_deadline - t_now;
+    const float f_data = (float)a_data, f_wl = (float)a_wl, f_rem = (float)(a_rem > 0 ? a_rem : 0.0);
     {
         uint64_t nb = new_bits;
         int r = 0;
         while (nb != 0ull) {
             const int j = __ffsll((unsigned long long)nb) - 1;
             nb &= nb - 1ull;
-            const int h = __shfl(a_home, j);
-            const double rem_d = __shfl(a_deadline, j) - t_now;
-            const float c1 = (float)__shfl(q_obs, j), c2 = (float)__shfl(a_data, j), c3 = (float)__shfl(a_wl, j);
-            const float c4 = (float)(rem_d > 0 ? rem_d : 0.0);
+            const int h = rl_i(a_home, j);
+            const float c1 = (float)rl_i(q_obs, j), c2 = rl_f(f_data, j), c3 = rl_f(f_wl, j), c4 = rl_f(f_rem, j);
             float* row = out.pend_obs + (env * PCAP + r) * (int64_t)w;
             for (int c = lane; c < w; c += 64) {
                 float v;
@@ -500,6 +569,11 @@ struct ems_handle {
     double* d_lat_log = nullptr;
     double* d_sort_scratch = nullptr;
     int32_t* d_err = nullptr;
+    // scalar chain computed ahead by scaled_chain_kernel: rows [chain_first, chain_first + chain_rows) of steps
+    double* d_chain_clock = nullptr;   // [n_envs] sim_time after the last computed row
+    double* d_chain_win = nullptr;     // [CHAIN_ROWS][n_envs]
+    int32_t* d_chain_n = nullptr;      // [CHAIN_ROWS][n_envs]
+    int32_t chain_first = 0, chain_rows = 0;
     bool was_reset = false;
 };
 
@@ -530,6 +604,25 @@ ScaledParams make_sparams(const ems_handle* h)
     p.n_envs = h->n_envs;
     p.lat_cap = h->lat_cap;
     return p;
+}
+
+// Makes sure the scalar chain of step `step_no` (0 = reset) is in the buffers; returns its row through `row`.
+int ensure_chain(ems_handle* h, const ScaledParams& p, int step_no, hipStream_t s, int* row)
+{
+    if (step_no == 0 || step_no < h->chain_first || step_no >= h->chain_first + h->chain_rows) {
+        if (step_no != 0 && step_no != h->chain_first + h->chain_rows)
+            return em::fail(EM_ERR_STATE, "scalar chain out of sequence (step %d, have %d..%d)", step_no, h->chain_first,
+                            h->chain_first + h->chain_rows - 1);
+        const dim3 grid((unsigned)((h->n_envs + 255) / 256)), block(256);
+        hipLaunchKernelGGL(scaled_chain_kernel, grid, block, 0, s, p, h->d_const, h->d_chain_clock, h->d_chain_win,
+                           h->d_chain_n, step_no, (int)CHAIN_ROWS);
+        const int rc = em::hip_check(hipGetLastError(), "scaled_chain_kernel launch");
+        if (rc) return rc;
+        h->chain_first = step_no;
+        h->chain_rows = CHAIN_ROWS;
+    }
+    *row = step_no - h->chain_first;
+    return EM_OK;
 }
 
 int check_sout(const ems_step_out* out)
@@ -577,6 +670,9 @@ int ems_create(const em_config* cfg, int32_t n_deciders, int64_t n_envs, int dev
     }
     if (e == hipSuccess) e = hipMalloc(&h->d_err, sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(h->d_err, 0, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->d_chain_clock, sizeof(double) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMalloc(&h->d_chain_win, sizeof(double) * (size_t)n_envs * CHAIN_ROWS);
+    if (e == hipSuccess) e = hipMalloc(&h->d_chain_n, sizeof(int32_t) * (size_t)n_envs * CHAIN_ROWS);
     if (e == hipSuccess && h->lat_cap > 0) {
         e = hipMalloc(&h->d_lat_log, sizeof(double) * (size_t)n_envs * (size_t)h->lat_cap);
         if (e == hipSuccess && h->lat_cap * 8 > 64 * 1024)
@@ -599,6 +695,9 @@ int ems_destroy(ems_handle* h)
     if (h->d_lat_log) (void)hipFree(h->d_lat_log);
     if (h->d_sort_scratch) (void)hipFree(h->d_sort_scratch);
     if (h->d_err) (void)hipFree(h->d_err);
+    if (h->d_chain_clock) (void)hipFree(h->d_chain_clock);
+    if (h->d_chain_win) (void)hipFree(h->d_chain_win);
+    if (h->d_chain_n) (void)hipFree(h->d_chain_n);
     delete h;
     return EM_OK;
 }
@@ -613,9 +712,13 @@ int ems_reset(ems_handle* h, int has_seed, uint64_t seed, const ems_step_out* ou
     h->was_reset = true;
     h->step = 0;
     const ScaledParams p = make_sparams(h);
+    int row = 0;
+    const int crc = ensure_chain(h, p, 0, (hipStream_t)stream, &row);
+    if (crc) return crc;
     const dim3 grid((unsigned)((h->n_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     hipLaunchKernelGGL((scaled_env_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
-                       nullptr, *out, h->d_lat_log, h->d_err);
+                       nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                       h->d_lat_log, h->d_err);
     return em::hip_check(hipGetLastError(), "scaled_env_kernel<reset> launch");
 }
 
@@ -629,9 +732,13 @@ int ems_step(ems_handle* h, const int32_t* placement, const float* resource, int
     if (rc) return rc;
     ScaledParams p = make_sparams(h);
     p.by_slot = actions_by_slot ? 1 : 0;
+    int row = 0;
+    const int crc = ensure_chain(h, p, h->step + 1, (hipStream_t)stream, &row);
+    if (crc) return crc;
     const dim3 grid((unsigned)((h->n_envs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     hipLaunchKernelGGL((scaled_env_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
-                       resource, *out, h->d_lat_log, h->d_err);
+                       resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                       h->d_lat_log, h->d_err);
     const int lrc = em::hip_check(hipGetLastError(), "scaled_env_kernel<step> launch");
     if (lrc) return lrc;
     h->step += 1;
