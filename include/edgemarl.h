@@ -313,6 +313,67 @@ int em_adam_step(float *actor_param, const float *actor_grad, float *actor_m, fl
                  int64_t n_critic, double lr_critic, int64_t step, double beta1, double beta2, double eps,
                  double max_grad_norm, float *norms2_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Grouped MLP kernels for the scaled topology (BASELINE.json configs[4]): IPPO = one actor and one local critic per
+ * decider agent, MAPPO = one shared actor (n_groups == 1).  Build-defined: the reference's IPPO is RLlib's PPO with
+ * one policy per agent (MRRL.PY:611-638, un-vendored ray[rllib]); here every independent learner runs the reference's
+ * own MAPPO arithmetic (mappo_algorithm.py) on its own transitions.  Rows are served in GROUPS: positions
+ * [group_off[g], group_off[g+1]) of the grouped order use network g; perm maps a position to its row in x and in the
+ * per-row arrays (NULL = identity; group_off NULL needs n_groups == 1).  split = workgroups per group.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct em_gmlp {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;   /* network 0, torch.nn.Linear layout as em_mlp3 */
+    int64_t group_stride;                       /* floats between the same parameter of consecutive networks */
+    int32_t in_dim, hidden, out_dim, n_groups;  /* hidden 64, in_dim <= 80, out_dim <= 80 */
+} em_gmlp;
+
+/* y[row][out_dim] = MLP_g(x[row]) (MAPPOActor.forward / MAPPOCritic.forward, mappo_algorithm.py:36-41,83-90). */
+int em_gmlp_forward(const em_gmlp *net, const float *x, int64_t ldx, int64_t n_rows, const int64_t *group_off,
+                    const int32_t *perm, int32_t split, float *y, void *stream);
+/* MAPPO.get_actions + MAPPOTrainer._format_env_actions per row (mappo_algorithm.py:189-224, mappo_trainer.py:125-158):
+ * a = mu + exp(log_std) * eps (noise [rows][out_dim] pre-drawn, or NULL for the in-kernel Philox/Box-Muller stream
+ * addressed by (seed; env_offset + ent_env, episode, rng_step, ent_agent)), log-prob, placement = first argmax of the
+ * first n_place components (0 if all within 1e-8 of 0), resource = float32(0.1 + 0.9 clip((tanh(a[n_place]) + 1)/2)),
+ * written to placement/resource[ent_dst[row]].  log_std: network 0's, same group stride. */
+int em_gmlp_policy(const em_gmlp *actor, const float *log_std, const float *x, int64_t ldx, int64_t n_rows,
+                   const int64_t *group_off, const int32_t *perm, int32_t split, const float *noise, int explore,
+                   uint64_t seed, uint32_t episode, uint32_t rng_step, uint64_t env_offset, const int32_t *ent_env,
+                   const int32_t *ent_agent, const int32_t *ent_dst, int32_t n_place, float *ent_action, float *ent_logp,
+                   int32_t *placement, float *resource, void *stream);
+/* MAPPO.get_values per row (mappo_algorithm.py:226-239): value[row] = critic_g(x[row]) de-normalised. */
+int em_gmlp_value(const em_gmlp *critic, const float *x, int64_t ldx, int64_t n_rows, const int64_t *group_off,
+                  const int32_t *perm, int32_t split, float value_norm_mean, float value_norm_var, float *value,
+                  void *stream);
+/* Floats per slab row / per network gradient (+3 loss sums): [w1|b1|w2|b2|w3|b3|(log_std)|3]. */
+int64_t em_gmlp_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor);
+/* One epoch of MAPPO.update per group (mappo_algorithm.py:293,302-309,317-320): advantages normalised with the
+ * group's moments3[g] = {count, sum, sum of squares} (global over ranks; fewer than 2 transitions: variance 0), means
+ * over the group's count.  grad_out [n_groups][slab_floats - 3], loss3_out [n_groups][3] = {sum min(surr), sum
+ * entropy, rows}; slab = scratch [n_groups][4 * split][slab_floats]. */
+int em_gmlp_actor_grad(const em_gmlp *actor, const float *log_std, const float *x, int64_t ldx, const float *action,
+                       const float *old_logp, const float *adv, const double *moments3, int64_t n_rows,
+                       const int64_t *group_off, const int32_t *perm, int32_t split, float clip, float entropy_coeff,
+                       float *slab, float *grad_out, float *loss3_out, void *stream);
+/* Value loss per group (mappo_algorithm.py:303,312-314) on per-row returns; loss3_out = {sum e^2, 0, rows}. */
+int em_gmlp_critic_grad(const em_gmlp *critic, const float *x, int64_t ldx, const float *ret, const double *moments3,
+                        int64_t n_rows, const int64_t *group_off, const int32_t *perm, int32_t split,
+                        float value_loss_coeff, float value_norm_mean, float value_norm_var, float *slab, float *grad_out,
+                        float *loss3_out, void *stream);
+/* clip_grad_norm_ per network (mappo_algorithm.py:328-329) + Adam (:331-332) on [n_groups][n_per_group] flat buffers. */
+int em_group_adam(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n_per_group,
+                  int64_t n_groups, double lr, int64_t step, double beta1, double beta2, double eps, double max_grad_norm,
+                  float *norms_out, void *stream);
+/* moments3[g] = {rows, sum, sum of squares} of adv over group g, fixed summation order. */
+int em_group_moments(const float *adv, const int64_t *group_off, const int32_t *perm, int32_t n_groups, double *moments3,
+                     void *stream);
+/* MAPPO.compute_gae (mappo_algorithm.py:241-262) for independent learners: one chain per (environment, agent) over the
+ * agent's own transitions, next_value = 0 at the end of the recorded horizon.  reward/done/k/first are dense
+ * [horizon][n_envs] (k = entries of the step, first = index of its first entry), ent_agent/ent_value per entry;
+ * chain_state = scratch [n_envs][n_agents][2] doubles. */
+int em_gae_agents(int64_t n_envs, int32_t horizon, int32_t n_agents, const double *reward_tb, const uint8_t *done_tb,
+                  const uint8_t *k_tb, const int32_t *first_tb, const int32_t *ent_agent, const float *ent_value,
+                  double gamma, double lam, double *chain_state, float *ent_adv, float *ent_ret, void *stream);
+
 int em_abi_version(void);
 const char *em_last_error(void);
 

@@ -49,6 +49,13 @@ class EmMlp3(C.Structure):
                 ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32)]
 
 
+class EmGmlp(C.Structure):
+    """ctypes image of ``em_gmlp``: n_groups networks of one shape, ``group_stride`` floats apart."""
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p), ("group_stride", C.c_int64),
+                ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32), ("n_groups", C.c_int32)]
+
+
 class EmRollout(C.Structure):
     _fields_ = [("n_envs", C.c_int64), ("capacity_entries", C.c_int64), ("capacity_steps", C.c_int64),
                 ("n_nodes", C.c_int32), ("horizon", C.c_int32)] + [
@@ -118,6 +125,21 @@ def lib() -> C.CDLL:
     L.em_ppo_actor_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp, i64, vp, vp, vp]
     L.em_ppo_critic_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, i64, i64, f32, f32, f32, vp, i64, vp, vp, vp]
     L.em_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, vp, vp, vp, vp, i64, f64, i64, f64, f64, f64, f64, vp, vp]
+    G = C.POINTER(EmGmlp)
+    L.em_gmlp_forward.argtypes = [G, vp, i64, i64, vp, vp, C.c_int32, vp, vp]
+    L.em_gmlp_policy.argtypes = [G, vp, vp, i64, i64, vp, vp, C.c_int32, vp, i32, u64, C.c_uint32, C.c_uint32, u64,
+                                 vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.em_gmlp_value.argtypes = [G, vp, i64, i64, vp, vp, C.c_int32, f32, f32, vp, vp]
+    L.em_gmlp_slab_floats.argtypes = [C.c_int32, C.c_int32, i32]
+    L.em_gmlp_slab_floats.restype = i64
+    L.em_gmlp_actor_grad.argtypes = [G, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, C.c_int32, f32, f32, vp, vp, vp, vp]
+    L.em_gmlp_critic_grad.argtypes = [G, vp, i64, vp, vp, i64, vp, vp, C.c_int32, f32, f32, f32, vp, vp, vp, vp]
+    L.em_group_adam.argtypes = [vp, vp, vp, vp, i64, i64, f64, i64, f64, f64, f64, f64, vp, vp]
+    L.em_group_moments.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
+    L.em_gae_agents.argtypes = [i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]
+    for name in ("em_gmlp_forward", "em_gmlp_policy", "em_gmlp_value", "em_gmlp_actor_grad", "em_gmlp_critic_grad",
+                 "em_group_adam", "em_group_moments", "em_gae_agents"):
+        getattr(L, name).restype = C.c_int
     for name in ("em_mlp3_forward", "em_rollout_index", "em_policy_step", "em_gae", "em_ppo_actor_grad",
                  "em_ppo_critic_grad", "em_adam_step"):
         getattr(L, name).restype = C.c_int

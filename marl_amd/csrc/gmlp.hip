@@ -1,0 +1,917 @@
+// gmlp.hip - GROUPED 3-layer MLP kernels on the f32 matrix cores for the scaled topology (BASELINE.json configs[4]):
+//   * IPPO: one actor (S+4 -> 64 -> 64 -> S+1) and one local critic (S+4 -> 64 -> 64 -> 1) PER DECIDER AGENT, the PPO
+//     maths of the reference's MAPPO applied per agent (mappo_algorithm.py:62-71,241-262,293-332; the reference's own
+//     IPPO lives in un-vendored ray[rllib], MRRL.PY:611-638: parity unpinned);
+//   * MAPPO on the scaled topology: the same kernels with ONE group (shared actor, mappo_algorithm.py:16-71).
+// Generalises mlp3_fwd_kernel / mlp3_bwd_kernel (mappo_fwd.hip, mappo_bwd.hip) in two directions: output widths up
+// to 80 (OT tiles of 16) and groups of rows that use different networks.
+//
+// Mapping: a workgroup serves ONE group (network): it stages that network's weights into LDS once and its four
+// wavefronts stride over the group's 16-row tiles; `split` workgroups share a group (256 agents x split 1 fills the
+// 256 CUs with one agent per CU; a single shared network uses split = 256).  Rows of a group are addressed through a
+// permutation (entries stay where the rollout wrote them; only an index is sorted by agent).  The MFMA formulation
+// is the transposed problem H^T = W . X^T of mappo_fwd.hip: the accumulator tile of a layer is register for register
+// the B operand of the next layer.  Weight gradients accumulate in registers over the group's tiles and leave as one
+// slab row per (group, wavefront); reduce_group_slabs sums them in fixed order (bitwise reproducible, no atomics).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "edgemarl.h"
+#include "em_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int HID = 64;
+constexpr int TS = 17;      // row stride of the transpose scratch (floats)
+constexpr int S2 = 66;      // LDS row stride of 64-wide weight matrices (2*odd: conflict-free fragment reads)
+constexpr float HALF_LOG_2PI = 0.91893853320467274f;
+
+__device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ inline void box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
+{
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.2831853071795865f * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+enum { P_NOISE = 8 };
+enum { MODE_PLAIN = 0, MODE_POLICY = 1, MODE_VALUE = 2 };
+
+struct GArgs {
+    em_gmlp net;
+    const float* x;            // [rows][ldx]
+    int64_t ldx, n_rows;
+    const int64_t* group_off;  // [n_groups + 1] positions in the grouped order, or nullptr (one group = all rows)
+    const int32_t* perm;       // [n_rows] grouped position -> row, or nullptr (identity)
+    int32_t split, pad0;       // workgroups per group
+    // forward outputs
+    float* y;                  // MODE_PLAIN: [rows][out_dim]
+    const float* log_std;      // [out_dim] of network 0 (same group stride as the network)
+    const float* noise;        // [rows][out_dim] standard normal draws or nullptr (in-kernel Philox + Box-Muller)
+    float* ent_action;         // [rows][out_dim]
+    float* ent_logp;           // [rows]
+    const int32_t* ent_env;    // [rows]
+    const int32_t* ent_agent;  // [rows]
+    const int32_t* ent_dst;    // [rows] index into placement/resource
+    int32_t* placement;
+    float* resource;
+    int32_t n_place, explore;  // the first n_place outputs are placement logits, output n_place is the resource share
+    uint32_t seed_lo, seed_hi, episode, step, env_offset, pad1;
+    float* value;              // MODE_VALUE: [rows]
+    float norm_mean, norm_scale;
+    // backward
+    float* slab;               // [n_groups][split * 4][slab_stride]
+    int64_t slab_stride;
+    const float* action;       // [rows][out_dim]
+    const float* old_logp;     // [rows]
+    const float* adv;          // [rows] un-normalised advantages
+    const float* ret;          // [rows] returns (critic)
+    const double* moments;     // [n_groups][3] {count, sum, sum of squares} of the group's advantages (global)
+    float clip, ecoef, vcoef, pad2;
+};
+
+// LDS carve-up shared by forward and backward: W1 [64][S1] | W2 [64][S2] | W3 [16*OT][S2] | b1[64] b2[64] b3[16*OT] ls[16*OT]
+template <int KU, int OT>
+struct Lds {
+    static constexpr int K1P = KU * 16;
+    static constexpr int S1 = (K1P + 2) | 2;
+    static constexpr int W1 = 0, W2 = W1 + HID * S1, W3 = W2 + HID * S2, B1 = W3 + 16 * OT * S2, B2 = B1 + HID,
+                         B3 = B2 + HID, LS = B3 + 16 * OT, END = LS + 16 * OT;
+};
+
+template <int KU, int OT>
+__device__ inline void stage_weights(float* lds, const em_gmlp& net, const float* log_std, int g)
+{
+    using L = Lds<KU, OT>;
+    const int K1 = net.in_dim, O = net.out_dim;
+    const int64_t go = (int64_t)g * net.group_stride;
+    const float* w1 = net.w1 + go;
+    const float* w2 = net.w2 + go;
+    const float* w3 = net.w3 + go;
+    for (int i = threadIdx.x; i < HID * L::K1P; i += 256) {
+        const int r = i / L::K1P, k = i - r * L::K1P;
+        lds[L::W1 + r * L::S1 + k] = k < K1 ? w1[r * K1 + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < HID * HID; i += 256) lds[L::W2 + (i >> 6) * S2 + (i & 63)] = w2[i];
+    for (int i = threadIdx.x; i < 16 * OT * HID; i += 256) lds[L::W3 + (i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? w3[i] : 0.0f;
+    if (threadIdx.x < HID) {
+        lds[L::B1 + threadIdx.x] = net.b1[go + threadIdx.x];
+        lds[L::B2 + threadIdx.x] = net.b2[go + threadIdx.x];
+    }
+    if (threadIdx.x < 16 * OT) {
+        lds[L::B3 + threadIdx.x] = (int)threadIdx.x < O ? net.b3[go + threadIdx.x] : 0.0f;
+        lds[L::LS + threadIdx.x] = (log_std && (int)threadIdx.x < O) ? log_std[go + threadIdx.x] : 0.0f;
+    }
+}
+
+// forward of one 16-row tile; xb = x fragment (row c, features 16u + 4q + r)
+template <int KU, int OT>
+__device__ inline void forward_tile(const float* lds, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
+                                    f32x4 (&y)[OT])
+{
+    using L = Lds<KU, OT>;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[t][r] = lds[L::B1 + 16 * t + 4 * q + r];
+#pragma unroll
+    for (int s = 0; s < KU * 4; ++s) {
+        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W1 + (16 * t + c) * L::S1 + k], xb[s], h1[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h1[t][r] = fmaxf(h1[t][r], 0.0f);
+            h2[t][r] = lds[L::B2 + 16 * t + 4 * q + r];
+        }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W2 + (16 * t + c) * S2 + k], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[ot][r] = lds[L::B3 + 16 * ot + 4 * q + r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+            y[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + c) * S2 + k], h2[s >> 2][s & 3], y[ot], 0, 0, 0);
+        }
+    }
+    // y[ot][r] = out[row c][o = 16 ot + 4q + r]
+}
+
+template <int KU>
+__device__ inline void load_x_frag(const GArgs& a, int64_t grow, bool valid, int q, float (&xb)[KU * 4])
+{
+    const int K1 = a.net.in_dim;
+    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    const float* xr = a.x + (valid ? grow : 0) * a.ldx;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int k = 16 * u + 4 * q;
+        if (vec_ok && k + 3 < K1) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + k);
+            xb[u * 4 + 0] = v.x; xb[u * 4 + 1] = v.y; xb[u * 4 + 2] = v.z; xb[u * 4 + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+        }
+    }
+    if (!valid) {
+#pragma unroll
+        for (int s = 0; s < KU * 4; ++s) xb[s] = 0.0f;
+    }
+}
+
+template <int KU, int OT, int MODE>
+__global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    using L = Lds<KU, OT>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int O = a.net.out_dim;
+    const int g = blockIdx.x / a.split, part = blockIdx.x - g * a.split;
+    const int64_t r0 = a.group_off ? a.group_off[g] : 0, r1 = a.group_off ? a.group_off[g + 1] : a.n_rows;
+    const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
+    if ((int64_t)part * 4 >= n_tiles) return;          // uniform over the workgroup: safe before the barrier
+    stage_weights<KU, OT>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g);
+    __syncthreads();
+
+    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
+        const int64_t row = tile * 16 + c;
+        const bool valid = row < n_rows;
+        const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
+        float xb[KU * 4];
+        load_x_frag<KU>(a, grow, valid, q, xb);
+        f32x4 h1[4], h2[4], y[OT];
+        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y);
+
+        if constexpr (MODE == MODE_PLAIN) {
+            if (valid) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * ot + 4 * q + r < O) a.y[grow * O + 16 * ot + 4 * q + r] = y[ot][r];
+            }
+        } else if constexpr (MODE == MODE_VALUE) {
+            if (valid && q == 0) a.value[grow] = y[0][0] * a.norm_scale + a.norm_mean;   // denormalize, mappo_algorithm.py:384-386
+        } else {
+            // ---- policy epilogue: rsample + log-prob (mappo_algorithm.py:62-71,209-213), action formatting
+            //      (mappo_trainer.py:125-158) --------------------------------------------------------------
+            const int n = a.n_place;
+            const int env = valid ? a.ent_env[grow] : 0;
+            const int agent = valid ? a.ent_agent[grow] : 0;
+            float lp = 0.0f, best = -__builtin_inff(), res_raw = 0.0f;
+            int best_i = 1 << 20;
+            bool all_zero = true;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.explore && !a.noise) {
+                    const uint4 rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step,
+                                              (P_NOISE << 24) | ((uint32_t)agent << 8) | (uint32_t)(ot << 2) | (uint32_t)q,
+                                              a.seed_lo, a.seed_hi);
+                    box_muller(rnd.x, rnd.y, z[0], z[1]);
+                    box_muller(rnd.z, rnd.w, z[2], z[3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * ot + 4 * q + r;
+                    const bool on = o < O;
+                    float v = y[ot][r];
+                    if (a.explore && on) {
+                        const float ls = lds[L::LS + o];
+                        const float sd = expf(ls);
+                        const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
+                        v = y[ot][r] + e * sd;                                  // rsample, mappo_algorithm.py:65
+                        const float d = v - y[ot][r];
+                        lp += -(d * d) / (2.0f * (sd * sd)) - ls - HALF_LOG_2PI;   // Normal.log_prob
+                    }
+                    if (on && valid) a.ent_action[grow * O + o] = v;
+                    if (on && o < n) {
+                        if (fabsf(v) > 1e-8f) all_zero = false;
+                        if (v > best) { best = v; best_i = o; }
+                    }
+                    if (o == n) res_raw = v;
+                }
+            }
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {   // combine the four lanes (q = 0..3) that share a batch row
+                lp += __shfl_xor(lp, m);
+                const float ob = __shfl_xor(best, m);
+                const int oi = __shfl_xor(best_i, m);
+                const int oz = __shfl_xor((int)all_zero, m);
+                res_raw += __shfl_xor(res_raw, m);
+                if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+                all_zero = all_zero && (oz != 0);
+            }
+            if (valid && q == 0) {
+                a.ent_logp[grow] = a.explore ? lp : 0.0f;                  // eval: log_prob = 0 (mappo_algorithm.py:218)
+                const int place = all_zero ? 0 : best_i % n;
+                double norm = (tanh((double)res_raw) + 1.0) / 2.0;        // mappo_trainer.py:148-152
+                norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
+                const int64_t dst = a.ent_dst[grow];
+                a.placement[dst] = place;
+                a.resource[dst] = (float)(0.1 + 0.9 * norm);
+            }
+        }
+    }
+}
+
+// fused forward-recompute + loss + backward for the rows of one group (mlp3_bwd_kernel generalised)
+template <int KU, int OT, bool ACTOR>
+__global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    using L = Lds<KU, OT>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int K1 = a.net.in_dim, O = a.net.out_dim;
+    const int g = blockIdx.x / a.split, part = blockIdx.x - g * a.split;
+    const int64_t r0 = a.group_off ? a.group_off[g] : 0, r1 = a.group_off ? a.group_off[g + 1] : a.n_rows;
+    const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
+    float* scr = lds + L::END + wave * (HID * TS);     // per-wavefront transpose scratch [64][TS]
+    stage_weights<KU, OT>(lds, a.net, ACTOR ? a.log_std : nullptr, g);
+    __syncthreads();
+
+    f32x4 gW1[4][KU], gW2[4][4], gW3[OT][4], gb1[4], gb2[4], gb3[OT], gls[OT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) gW1[t][u] = zero4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gW2[t][u] = zero4;
+        gb1[t] = zero4; gb2[t] = zero4;
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gW3[ot][t] = zero4;
+        gb3[ot] = zero4; gls[ot] = zero4;
+    }
+    float loss_sum = 0.0f, aux_sum = 0.0f, cnt_sum = 0.0f;
+
+    // the group's own batch statistics: PPO normalises advantages over the learner's batch (mappo_algorithm.py:293)
+    const double m_n = a.moments[3 * g], m_s1 = a.moments[3 * g + 1], m_s2 = a.moments[3 * g + 2];
+    const float inv_L = m_n > 0.0 ? (float)(1.0 / m_n) : 0.0f;
+    float adv_mean = 0.0f, adv_den = 1.0f, ent_row = 0.0f;
+    if constexpr (ACTOR) {
+        const double mean = m_n > 0.0 ? m_s1 / m_n : 0.0;
+        // torch.std (unbiased); a learner with fewer than two transitions gets variance 0 (torch would give NaN)
+        double var = m_n > 1.0 ? (m_s2 - m_s1 * m_s1 / m_n) / (m_n - 1.0) : 0.0;
+        if (!(var > 0.0)) var = 0.0;
+        adv_mean = (float)mean;
+        adv_den = (float)sqrt(var) + 1e-8f;
+        for (int o = 0; o < O; ++o) ent_row += 0.5f + HALF_LOG_2PI + lds[L::LS + o];            // Normal.entropy summed
+    }
+
+    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
+        const int64_t row = tile * 16 + c;
+        const bool valid = row < n_rows;
+        const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
+        float xb[KU * 4];
+        load_x_frag<KU>(a, grow, valid, q, xb);
+        float p_adv = 0.0f, p_old = 0.0f, p_ret = 0.0f;
+        if (valid) {
+            if constexpr (ACTOR) { p_adv = a.adv[grow]; p_old = a.old_logp[grow]; }
+            else p_ret = a.ret[grow];
+        }
+        f32x4 h1[4], h2[4], y[OT], dy[OT];
+        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y);
+
+        // ---- loss and dL/dy in accumulator layout: dy[ot][r] = d/d out[row c][o = 16 ot + 4q + r] ------------
+        if constexpr (ACTOR) {
+            float lp = 0.0f;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * ot + 4 * q + r;
+                    float d = 0.0f;
+                    if (o < O && valid) {
+                        const float ls = lds[L::LS + o], sd = expf(ls);
+                        d = a.action[grow * O + o] - y[ot][r];
+                        lp += -(d * d) / (2.0f * (sd * sd)) - ls - HALF_LOG_2PI;
+                    }
+                    dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
+                }
+            lp += __shfl_xor(lp, 16);
+            lp += __shfl_xor(lp, 32);
+            float g_lp = 0.0f;
+            if (valid) {
+                const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
+                const float ratio = expf(lp - p_old);                       // :306
+                const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+                const float rc = fminf(fmaxf(ratio, lo), hi);
+                const float su1 = ratio * A, su2 = rc * A;                  // :307-308
+                const float in_range = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+                // d min(s1,s2)/d ratio with autograd's tie rule (equal inputs share the gradient)
+                const float wgt = su1 < su2 ? 1.0f : (su1 == su2 ? 0.5f + 0.5f * in_range : in_range);
+                g_lp = -(A * ratio * wgt) * inv_L;                          // d(-mean(min))/d logp
+                if (q == 0) { loss_sum += fminf(su1, su2); cnt_sum += 1.0f; aux_sum += ent_row; }
+            }
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * ot + 4 * q + r;
+                    const float d = dy[ot][r];
+                    float out = 0.0f;
+                    if (o < O && valid) {
+                        const float sd = expf(lds[L::LS + o]);
+                        const float iv = 1.0f / (sd * sd);
+                        out = g_lp * d * iv;                                // d logp / d mu
+                        gls[ot][r] += g_lp * (d * d * iv - 1.0f) - a.ecoef * inv_L;   // d logp / d log_std ; entropy bonus
+                    }
+                    dy[ot][r] = out;
+                }
+        } else {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) dy[ot] = zero4;
+            if (valid && q == 0) {
+                const float e = (y[0][0] - a.norm_mean) / a.norm_scale - (p_ret - a.norm_mean) / a.norm_scale;   // :312-314
+                loss_sum += e * e;
+                cnt_sum += 1.0f;
+                dy[0][0] = a.vcoef * inv_L * e / a.norm_scale;              // d(vcoef * 0.5 * mean(e^2)) / dv
+            }
+        }
+
+        // ---- backward through layers 3 and 2 ------------------------------------------------------------------
+        f32x4 dz2[4], dz1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dz2[t] = zero4;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            gb3[ot] += dy[ot];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 16 ot + 4q + r
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + 4 * q + r) * S2 + 16 * t + c], dy[ot][r],
+                                                                  dz2[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
+            dz1[t] = zero4;
+            gb2[t] += dz2[t];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
+            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W2 + k * S2 + 16 * t + c], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
+            gb1[t] += dz1[t];
+        }
+
+        // ---- weight gradients: reduction over the 16 batch rows of the tile ------------------------------------
+        float tr_a[4][4], tr_b[4][4];
+        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = m[t][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) out[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
+        transpose64(h2, tr_b);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            float tr_y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(4 * q + r) * TS + c] = dy[ot][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tr_y[s] = scr[c * TS + 4 * s + q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    gW3[ot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[ot][t], 0, 0, 0);
+        }
+        // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
+        transpose64(dz2, tr_a);
+        transpose64(h1, tr_b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+                for (int t1 = 0; t1 < 4; ++t1)
+                    gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+        // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
+        transpose64(dz1, tr_a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t rb = tile * 16 + 4 * s + q;
+            const bool vb = rb < n_rows;
+            const int64_t gb = vb ? (a.perm ? (int64_t)a.perm[r0 + rb] : r0 + rb) : 0;
+            const float* xrow = a.x + gb * a.ldx;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int i = 16 * u + c;
+                const float xv = (vb && i < K1) ? xrow[i] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- this wavefront's slab row: [w1 | b1 | w2 | b2 | w3 | b3 | (log_std) | loss, aux, count] ---------------
+    float* out = a.slab + (((int64_t)g * a.split + part) * 4 + wave) * a.slab_stride;
+    const int o_b1 = HID * K1, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID, o_w3 = o_b2 + HID, o_b3 = o_w3 + O * HID;
+    const int o_ls = o_b3 + O, o_loss = ACTOR ? o_ls + O : o_ls;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * q + r;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int i = 16 * u + c;
+                if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+            }
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
+        }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * ot + 4 * q + r < O) out[o_w3 + (16 * ot + 4 * q + r) * HID + 16 * t + c] = gW3[ot][t][r];
+    // bias-type gradients: reduce the 16 lanes that share q (fixed butterfly order)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                gb1[t][r] += __shfl_xor(gb1[t][r], m);
+                gb2[t][r] += __shfl_xor(gb2[t][r], m);
+            }
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                gb3[ot][r] += __shfl_xor(gb3[ot][r], m);
+                gls[ot][r] += __shfl_xor(gls[ot][r], m);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        loss_sum += __shfl_xor(loss_sum, m);
+        aux_sum += __shfl_xor(aux_sum, m);
+        cnt_sum += __shfl_xor(cnt_sum, m);
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[o_b1 + 16 * t + 4 * q + r] = gb1[t][r];
+                out[o_b2 + 16 * t + 4 * q + r] = gb2[t][r];
+            }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * ot + 4 * q + r < O) {
+                    out[o_b3 + 16 * ot + 4 * q + r] = gb3[ot][r];
+                    if constexpr (ACTOR) out[o_ls + 16 * ot + 4 * q + r] = gls[ot][r];
+                }
+    }
+    if (lane == 0) { out[o_loss] = loss_sum; out[o_loss + 1] = aux_sum; out[o_loss + 2] = cnt_sum; }
+}
+
+// grads[g][p] = sum over the group's slab rows, fixed order; the last 3 columns (loss sums) go to loss3[g]
+__global__ __launch_bounds__(256) void reduce_group_slabs_kernel(const float* __restrict__ slab, int rows_per_group, int64_t stride,
+                                                                 float* __restrict__ grads, float* __restrict__ loss3)
+{
+    const int g = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= stride) return;
+    const float* s = slab + (int64_t)g * rows_per_group * stride + p;
+    float acc = 0.0f;
+    for (int r = 0; r < rows_per_group; ++r) acc += s[(int64_t)r * stride];
+    const int64_t np = stride - 3;
+    if (p < np) grads[(int64_t)g * np + p] = acc;
+    else loss3[(int64_t)g * 3 + (p - np)] = acc;
+}
+
+// clip_grad_norm_ (mappo_algorithm.py:328-329) + torch.optim.Adam (:331-332), one workgroup per parameter group
+struct GroupAdam {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n_per_group;
+    float step_size, one_m_beta1, beta2, one_m_beta2, eps, max_norm, bias_c2_sqrt, pad;
+};
+
+__global__ __launch_bounds__(256) void group_adam_kernel(const GroupAdam a, float* __restrict__ norms_out)
+{
+    const int64_t base = (int64_t)blockIdx.x * a.n_per_group;
+    __shared__ double red[256];
+    double ss = 0.0;
+    for (int64_t i = threadIdx.x; i < a.n_per_group; i += 256) ss += (double)a.grad[base + i] * (double)a.grad[base + i];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float total_norm = (float)sqrt(red[0]);
+    float coef = a.max_norm / (total_norm + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (threadIdx.x == 0 && norms_out) norms_out[blockIdx.x] = total_norm;
+    for (int64_t i = threadIdx.x; i < a.n_per_group; i += 256) {
+        const float gr = a.grad[base + i] * coef;
+        const float m = a.exp_avg[base + i] + (gr - a.exp_avg[base + i]) * a.one_m_beta1;
+        const float v = a.exp_avg_sq[base + i] * a.beta2 + a.one_m_beta2 * gr * gr;
+        a.exp_avg[base + i] = m;
+        a.exp_avg_sq[base + i] = v;
+        const float denom = sqrtf(v) / a.bias_c2_sqrt + a.eps;
+        a.param[base + i] = a.param[base + i] - a.step_size * (m / denom);
+    }
+}
+
+// {count, sum, sum of squares} of the float32 advantages of each group, fixed order (one workgroup per group)
+__global__ __launch_bounds__(256) void group_moments_kernel(const float* __restrict__ adv, const int64_t* __restrict__ group_off,
+                                                            const int32_t* __restrict__ perm, double* __restrict__ moments)
+{
+    const int g = blockIdx.x;
+    const int64_t r0 = group_off[g], r1 = group_off[g + 1];
+    __shared__ double red[2][256];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+        const double v = (double)adv[perm ? perm[i] : i];
+        s1 += v;
+        s2 += v * v;
+    }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { moments[3 * g] = (double)(r1 - r0); moments[3 * g + 1] = red[0][0]; moments[3 * g + 2] = red[1][0]; }
+}
+
+// GAE of independent learners: one chain per (environment, agent) over that agent's own transitions in time order
+// (MAPPO.compute_gae's recursion, mappo_algorithm.py:250-258, with the agent's own value estimates; next_value = 0
+// closes every chain, :284).  One lane per environment walks its steps backwards; chain state lives in `state`.
+__global__ __launch_bounds__(256) void gae_agents_kernel(int64_t B, int T, int D, const double* __restrict__ reward_tb,
+                                                         const uint8_t* __restrict__ done_tb, const uint8_t* __restrict__ k_tb,
+                                                         const int32_t* __restrict__ first_tb, const int32_t* __restrict__ ent_agent,
+                                                         const float* __restrict__ ent_value, double gamma, double lam,
+                                                         double* __restrict__ state, float* __restrict__ adv, float* __restrict__ ret)
+{
+#pragma clang fp contract(off)   // the float64 recursion in the reference's operation order, no fused multiply-add
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double* st = state + b * 2 * (int64_t)D;          // {gae, v_next} per agent
+    for (int d = 0; d < 2 * D; ++d) st[d] = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t i = (int64_t)t * B + b;
+        const int k = k_tb[i];
+        if (k == 0) continue;
+        const double r = reward_tb[i], nd = 1.0 - (double)done_tb[i];
+        const int64_t first = first_tb[i];
+        for (int j = 0; j < k; ++j) {
+            const int d = ent_agent[first + j];
+            const double v = (double)ent_value[first + j];
+            const double delta = r + gamma * st[2 * d + 1] * nd - v;
+            const double gae = delta + gamma * lam * nd * st[2 * d];
+            st[2 * d] = gae;
+            st[2 * d + 1] = v;
+            adv[first + j] = (float)gae;
+            ret[first + j] = (float)(gae + v);
+        }
+    }
+}
+
+int check_gnet(const em_gmlp* net)
+{
+    if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3)
+        return em::fail(EM_ERR_INVALID, "gmlp: null parameter pointer");
+    if (net->hidden != HID || net->in_dim < 1 || net->in_dim > 80 || net->out_dim < 1 || net->out_dim > 80)
+        return em::fail(EM_ERR_INVALID, "gmlp: unsupported shape (hidden 64, in_dim <= 80, out_dim <= 80)");
+    if (net->n_groups < 1 || net->n_groups > 65535) return em::fail(EM_ERR_INVALID, "gmlp: n_groups must be 1..65535");
+    return EM_OK;
+}
+
+size_t lds_bytes(int ku, int ot, bool bwd)
+{
+    const int s1 = (ku * 16 + 2) | 2;
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS : 0));
+}
+
+template <typename K>
+int set_lds(K kernel, size_t lds)
+{
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");
+    }
+    return EM_OK;
+}
+
+// in_dim <= 80 -> KU = 5 (one instantiation keeps the library small; narrower inputs are zero padded in LDS)
+template <int MODE>
+int launch_gfwd(const GArgs& ga, hipStream_t s)
+{
+    const int ot = (ga.net.out_dim + 15) / 16;
+    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(256);
+#define EM_GF(OT_)                                                                                    \
+    case OT_: {                                                                                       \
+        const size_t lds = lds_bytes(5, OT_, false);                                                  \
+        const int rc = set_lds(gmlp_fwd_kernel<5, OT_, MODE>, lds);                                   \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL((gmlp_fwd_kernel<5, OT_, MODE>), grid, block, lds, s, ga);                 \
+    } break
+    switch (ot) {
+        EM_GF(1); EM_GF(2); EM_GF(3); EM_GF(4); EM_GF(5);
+        default: return em::fail(EM_ERR_INVALID, "gmlp: unsupported out_dim");
+    }
+#undef EM_GF
+    return em::hip_check(hipGetLastError(), "gmlp_fwd_kernel launch");
+}
+
+template <bool ACTOR>
+int launch_gbwd(const GArgs& ga, hipStream_t s)
+{
+    const int ot = (ga.net.out_dim + 15) / 16;
+    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(256);
+#define EM_GB(OT_)                                                                                    \
+    case OT_: {                                                                                       \
+        const size_t lds = lds_bytes(5, OT_, true);                                                   \
+        const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR>, lds);                                  \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR>), grid, block, lds, s, ga);                \
+    } break
+    if constexpr (ACTOR) {
+        switch (ot) {
+            EM_GB(1); EM_GB(2); EM_GB(3); EM_GB(4); EM_GB(5);
+            default: return em::fail(EM_ERR_INVALID, "gmlp: unsupported out_dim");
+        }
+    } else {
+        switch (ot) {
+            EM_GB(1);
+            default: return em::fail(EM_ERR_INVALID, "gmlp critic: out_dim must be 1");
+        }
+    }
+#undef EM_GB
+    return em::hip_check(hipGetLastError(), "gmlp_bwd_kernel launch");
+}
+
+int check_rows(const em_gmlp* net, const float* x, int64_t ldx, int64_t n_rows, const int64_t* group_off, int split)
+{
+    if (!x || n_rows < 0 || ldx < net->in_dim) return em::fail(EM_ERR_INVALID, "gmlp: bad input rows");
+    if (net->n_groups > 1 && !group_off) return em::fail(EM_ERR_INVALID, "gmlp: group_off is required with several groups");
+    if (split < 1 || (int64_t)split * net->n_groups > (1 << 20)) return em::fail(EM_ERR_INVALID, "gmlp: bad split");
+    return EM_OK;
+}
+
+void fill_common(GArgs& ga, const em_gmlp* net, const float* x, int64_t ldx, int64_t n_rows, const int64_t* group_off,
+                 const int32_t* perm, int split)
+{
+    std::memset(&ga, 0, sizeof ga);
+    ga.net = *net; ga.x = x; ga.ldx = ldx; ga.n_rows = n_rows; ga.group_off = group_off; ga.perm = perm; ga.split = split;
+}
+
+}  // namespace
+
+extern "C" {
+
+int em_gmlp_forward(const em_gmlp* net, const float* x, int64_t ldx, int64_t n_rows, const int64_t* group_off,
+                    const int32_t* perm, int32_t split, float* y, void* stream)
+{
+    int rc = check_gnet(net);
+    if (rc) return rc;
+    rc = check_rows(net, x, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!y) return em::fail(EM_ERR_INVALID, "em_gmlp_forward: null output");
+    if (n_rows == 0) return EM_OK;
+    GArgs ga;
+    fill_common(ga, net, x, ldx, n_rows, group_off, perm, split);
+    ga.y = y;
+    return launch_gfwd<MODE_PLAIN>(ga, (hipStream_t)stream);
+}
+
+int em_gmlp_policy(const em_gmlp* actor, const float* log_std, const float* x, int64_t ldx, int64_t n_rows,
+                   const int64_t* group_off, const int32_t* perm, int32_t split, const float* noise, int explore, uint64_t seed,
+                   uint32_t episode, uint32_t rng_step, uint64_t env_offset, const int32_t* ent_env, const int32_t* ent_agent,
+                   const int32_t* ent_dst, int32_t n_place, float* ent_action, float* ent_logp, int32_t* placement,
+                   float* resource, void* stream)
+{
+    int rc = check_gnet(actor);
+    if (rc) return rc;
+    rc = check_rows(actor, x, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!log_std || !ent_env || !ent_agent || !ent_dst || !ent_action || !ent_logp || !placement || !resource)
+        return em::fail(EM_ERR_INVALID, "em_gmlp_policy: null argument");
+    if (n_place < 1 || n_place + 1 != actor->out_dim) return em::fail(EM_ERR_INVALID, "em_gmlp_policy: out_dim must be n_place + 1");
+    if (n_rows == 0) return EM_OK;
+    GArgs ga;
+    fill_common(ga, actor, x, ldx, n_rows, group_off, perm, split);
+    ga.log_std = log_std; ga.noise = noise; ga.ent_action = ent_action; ga.ent_logp = ent_logp; ga.ent_env = ent_env;
+    ga.ent_agent = ent_agent; ga.ent_dst = ent_dst; ga.placement = placement; ga.resource = resource; ga.n_place = n_place;
+    ga.explore = explore ? 1 : 0;
+    ga.seed_lo = (uint32_t)seed; ga.seed_hi = (uint32_t)(seed >> 32); ga.episode = episode; ga.step = rng_step;
+    ga.env_offset = (uint32_t)env_offset;
+    return launch_gfwd<MODE_POLICY>(ga, (hipStream_t)stream);
+}
+
+int em_gmlp_value(const em_gmlp* critic, const float* x, int64_t ldx, int64_t n_rows, const int64_t* group_off,
+                  const int32_t* perm, int32_t split, float value_norm_mean, float value_norm_var, float* value, void* stream)
+{
+    int rc = check_gnet(critic);
+    if (rc) return rc;
+    rc = check_rows(critic, x, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!value || critic->out_dim != 1) return em::fail(EM_ERR_INVALID, "em_gmlp_value: needs out_dim 1 and an output");
+    if (n_rows == 0) return EM_OK;
+    GArgs ga;
+    fill_common(ga, critic, x, ldx, n_rows, group_off, perm, split);
+    ga.value = value; ga.norm_mean = value_norm_mean; ga.norm_scale = sqrtf(value_norm_var + 1e-8f);
+    return launch_gfwd<MODE_VALUE>(ga, (hipStream_t)stream);
+}
+
+int64_t em_gmlp_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor)
+{
+    return (int64_t)HID * in_dim + HID + HID * HID + HID + (int64_t)out_dim * HID + out_dim + (is_actor ? out_dim : 0) + 3;
+}
+
+int em_gmlp_actor_grad(const em_gmlp* actor, const float* log_std, const float* x, int64_t ldx, const float* action,
+                       const float* old_logp, const float* adv, const double* moments3, int64_t n_rows,
+                       const int64_t* group_off, const int32_t* perm, int32_t split, float clip, float entropy_coeff,
+                       float* slab, float* grad_out, float* loss3_out, void* stream)
+{
+    int rc = check_gnet(actor);
+    if (rc) return rc;
+    rc = check_rows(actor, x, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!log_std || !action || !old_logp || !adv || !moments3 || !slab || !grad_out || !loss3_out)
+        return em::fail(EM_ERR_INVALID, "em_gmlp_actor_grad: null argument");
+    GArgs ga;
+    fill_common(ga, actor, x, ldx, n_rows, group_off, perm, split);
+    ga.log_std = log_std; ga.action = action; ga.old_logp = old_logp; ga.adv = adv; ga.moments = moments3;
+    ga.clip = clip; ga.ecoef = entropy_coeff; ga.slab = slab;
+    ga.slab_stride = em_gmlp_slab_floats(actor->in_dim, actor->out_dim, 1);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_gbwd<true>(ga, s);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((ga.slab_stride + 255) / 256), (unsigned)actor->n_groups);
+    hipLaunchKernelGGL(reduce_group_slabs_kernel, grid, dim3(256), 0, s, slab, split * 4, ga.slab_stride, grad_out, loss3_out);
+    return em::hip_check(hipGetLastError(), "gmlp actor grad launch");
+}
+
+int em_gmlp_critic_grad(const em_gmlp* critic, const float* x, int64_t ldx, const float* ret, const double* moments3,
+                        int64_t n_rows, const int64_t* group_off, const int32_t* perm, int32_t split, float value_loss_coeff,
+                        float value_norm_mean, float value_norm_var, float* slab, float* grad_out, float* loss3_out,
+                        void* stream)
+{
+    int rc = check_gnet(critic);
+    if (rc) return rc;
+    rc = check_rows(critic, x, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!ret || !moments3 || !slab || !grad_out || !loss3_out || critic->out_dim != 1)
+        return em::fail(EM_ERR_INVALID, "em_gmlp_critic_grad: bad argument");
+    GArgs ga;
+    fill_common(ga, critic, x, ldx, n_rows, group_off, perm, split);
+    ga.ret = ret; ga.moments = moments3; ga.vcoef = value_loss_coeff; ga.norm_mean = value_norm_mean;
+    ga.norm_scale = sqrtf(value_norm_var + 1e-8f); ga.slab = slab;
+    ga.slab_stride = em_gmlp_slab_floats(critic->in_dim, 1, 0);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_gbwd<false>(ga, s);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((ga.slab_stride + 255) / 256), (unsigned)critic->n_groups);
+    hipLaunchKernelGGL(reduce_group_slabs_kernel, grid, dim3(256), 0, s, slab, split * 4, ga.slab_stride, grad_out, loss3_out);
+    return em::hip_check(hipGetLastError(), "gmlp critic grad launch");
+}
+
+int em_group_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_per_group, int64_t n_groups,
+                  double lr, int64_t step, double beta1, double beta2, double eps, double max_grad_norm, float* norms_out,
+                  void* stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n_per_group < 1 || n_groups < 1 || step < 1)
+        return em::fail(EM_ERR_INVALID, "em_group_adam: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    GroupAdam a = {param, grad, exp_avg, exp_avg_sq, n_per_group, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                   (float)(1.0 - beta2), (float)eps, (float)max_grad_norm, (float)sqrt(bc2), 0.0f};
+    hipLaunchKernelGGL(group_adam_kernel, dim3((unsigned)n_groups), dim3(256), 0, (hipStream_t)stream, a, norms_out);
+    return em::hip_check(hipGetLastError(), "group adam launch");
+}
+
+int em_group_moments(const float* adv, const int64_t* group_off, const int32_t* perm, int32_t n_groups, double* moments3,
+                     void* stream)
+{
+    if (!adv || !group_off || !moments3 || n_groups < 1) return em::fail(EM_ERR_INVALID, "em_group_moments: bad argument");
+    hipLaunchKernelGGL(group_moments_kernel, dim3((unsigned)n_groups), dim3(256), 0, (hipStream_t)stream, adv, group_off, perm,
+                       moments3);
+    return em::hip_check(hipGetLastError(), "group moments launch");
+}
+
+int em_gae_agents(int64_t n_envs, int32_t horizon, int32_t n_agents, const double* reward_tb, const uint8_t* done_tb,
+                  const uint8_t* k_tb, const int32_t* first_tb, const int32_t* ent_agent, const float* ent_value, double gamma,
+                  double lam, double* chain_state, float* ent_adv, float* ent_ret, void* stream)
+{
+    if (!reward_tb || !done_tb || !k_tb || !first_tb || !ent_agent || !ent_value || !chain_state || !ent_adv || !ent_ret)
+        return em::fail(EM_ERR_INVALID, "em_gae_agents: null argument");
+    if (n_envs < 1 || horizon < 1 || n_agents < 1) return em::fail(EM_ERR_INVALID, "em_gae_agents: bad sizes");
+    hipLaunchKernelGGL(gae_agents_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_envs,
+                       horizon, n_agents, reward_tb, done_tb, k_tb, first_tb, ent_agent, ent_value, gamma, lam, chain_state,
+                       ent_adv, ent_ret);
+    return em::hip_check(hipGetLastError(), "gae agents launch");
+}
+
+}  // extern "C"
