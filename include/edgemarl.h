@@ -209,6 +209,36 @@ int ems_get_state(ems_handle *h, double *load, double *queue, double *sim_time, 
                   int64_t *counts, void *stream);
 int64_t ems_record_bytes(const ems_handle *h);
 
+/* Device buffers of one rollout on the scaled topology (RolloutBuffer, mappo_algorithm.py:93-131; all caller-owned).
+ * Entries = acting (environment, decider) transitions in (step, environment, arrival slot) order. */
+typedef struct ems_rollout {
+    int64_t n_envs, capacity_entries;
+    int32_t n_servers, n_deciders, horizon, pad;
+    float *ent_obs;        /* [E][n_servers+4]                                                        */
+    float *ent_action;     /* [E][n_servers+1] raw action vector                                      */
+    float *ent_logp;       /* [E]                                                                     */
+    float *ent_value;      /* [E] critic value of the entry's observation (independent learners)      */
+    int32_t *ent_env;      /* [E]                                                                     */
+    int32_t *ent_agent;    /* [E] decider id                                                          */
+    int32_t *ent_dst;      /* [E] env * EMS_PENDING_CAP + slot: where the entry's env action goes     */
+    float *ent_adv;        /* [E]                                                                     */
+    float *ent_ret;        /* [E]                                                                     */
+    double *reward_tb;     /* [T][B] ems_step_out.reward_seen                                         */
+    uint8_t *done_tb;      /* [T][B]                                                                  */
+    uint8_t *k_tb;         /* [T][B] entries of the step                                              */
+    int32_t *first_tb;     /* [T][B] first entry of the step                                          */
+    int64_t *counters;     /* [T+1]  entry base of each step; element 0 zeroed by the caller          */
+    int64_t *group_off;    /* [n_deciders+1] of the CURRENT step: positions of each group in perm     */
+    int32_t *perm;         /* [n_envs*EMS_PENDING_CAP] of the CURRENT step: position -> entry index   */
+    int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller     */
+} ems_rollout;
+
+/* Records which deciders act at step t (the pending lists ems_reset/ems_step returned): numbers the entries, copies
+ * their observation rows, and groups the step's entries by serving network (n_groups = n_deciders: one network per
+ * decider; 1: a shared network) for the grouped MLP kernels below. */
+int ems_rollout_index(const ems_rollout *ro, int32_t t, int32_t n_groups, const int32_t *n_pending,
+                      const int32_t *pend_decider, const float *pend_obs, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * MAPPO side (reference mappo_algorithm.py / mappo_trainer.py)
  * ---------------------------------------------------------------------------------------------- */

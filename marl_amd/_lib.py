@@ -65,6 +65,14 @@ class EmRollout(C.Structure):
             "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "scan_scratch", "counters", "err_flag")]
 
 
+class EmsRollout(C.Structure):
+    _fields_ = [("n_envs", C.c_int64), ("capacity_entries", C.c_int64), ("n_servers", C.c_int32), ("n_deciders", C.c_int32),
+                ("horizon", C.c_int32), ("pad", C.c_int32)] + [
+        (name, C.c_void_p) for name in (
+            "ent_obs", "ent_action", "ent_logp", "ent_value", "ent_env", "ent_agent", "ent_dst", "ent_adv", "ent_ret",
+            "reward_tb", "done_tb", "k_tb", "first_tb", "counters", "group_off", "perm", "err_flag")]
+
+
 _lib = None
 
 
@@ -109,6 +117,8 @@ def lib() -> C.CDLL:
     L.ems_get_exploration_counter.argtypes = [vp]
     L.ems_get_exploration_counter.restype = i64
     L.ems_get_state.argtypes = [vp] + [vp] * 7
+    L.ems_rollout_index.argtypes = [C.POINTER(EmsRollout), C.c_int32, C.c_int32, vp, vp, vp, vp]
+    L.ems_rollout_index.restype = C.c_int
     L.ems_record_bytes.argtypes = [vp]
     L.ems_record_bytes.restype = i64
     for name in ("ems_create", "ems_destroy", "ems_reset", "ems_step", "ems_episode_metrics", "ems_set_exploration",

@@ -108,7 +108,10 @@ class ScaledEdgeSimGym:
                                          C.byref(self._out), _stream_ptr(self.device)), "ems_reset")
         return self.n_pending, self.pend_decider, self.pend_obs
 
-    def step(self, placement: torch.Tensor, resource: torch.Tensor, by_slot: bool = False):
+    def step(self, placement: torch.Tensor, resource: torch.Tensor, by_slot: bool = False,
+             reward_seen_out: torch.Tensor | None = None, done_out: torch.Tensor | None = None):
+        """``reward_seen_out`` / ``done_out`` ([B] float64 / uint8, contiguous) redirect those two outputs of this call,
+        e.g. straight into a row of the rollout storage."""
         B = self.n_envs
         width = PENDING_CAP if by_slot else self.n_deciders
         if placement.dtype != torch.int32 or resource.dtype != torch.float32:
@@ -119,9 +122,17 @@ class ScaledEdgeSimGym:
             raise ValueError("actions must live on the environment's device")
         if not (placement.is_contiguous() and resource.is_contiguous()):
             raise ValueError("actions must be contiguous")
-        with torch.cuda.device(self.device):
-            _lib.check(self._L.ems_step(self._h, placement.data_ptr(), resource.data_ptr(), int(bool(by_slot)),
-                                        C.byref(self._out), _stream_ptr(self.device)), "ems_step")
+        o = self._out
+        if reward_seen_out is not None:
+            o.reward_seen = reward_seen_out.data_ptr()
+        if done_out is not None:
+            o.done = done_out.data_ptr()
+        try:
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.ems_step(self._h, placement.data_ptr(), resource.data_ptr(), int(bool(by_slot)),
+                                            C.byref(o), _stream_ptr(self.device)), "ems_step")
+        finally:
+            o.reward_seen, o.done = self.reward.data_ptr(), self.done.data_ptr()
         info = {"reward_raw": self.reward_raw, "emitted": self.emitted}
         return self.n_pending, self.pend_decider, self.pend_obs, self.reward, self.done, info
 

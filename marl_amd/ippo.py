@@ -1,0 +1,284 @@
+"""Independent PPO ("IPPO") and shared-actor PPO on the scaled topology (BASELINE.json configs[4]: 64 edge servers x
+256 decider agents), on the grouped MLP kernels of ``csrc/gmlp.hip``.
+
+The reference trains IPPO through RLlib's PPO with one policy per agent (``MRRL.PY:611-638``; ``ray[rllib]`` is not
+vendored): **parity with the reference is unpinned**.  The build defines the independent learner natively: every
+decider owns an actor (S+4 -> 64 -> 64 -> S+1, state-independent log_std) and a critic on its local observation
+(S+4 -> 64 -> 64 -> 1) and runs the reference's own MAPPO arithmetic on its own transitions: Gaussian policy and action
+formatting (``mappo_algorithm.py:62-71``, ``mappo_trainer.py:125-158``), GAE (``:241-262``) over the agent's own chain per
+environment, advantage normalisation over the learner's batch (``:293``), PPO-clip / value / entropy losses
+(``:302-320``), separate gradient clipping and Adam per network (``:328-332``).  ``shared=True`` replaces the 256 networks
+by one actor and one local critic shared by all deciders (parameter sharing; the central 17,408-wide critic of a
+scaled MAPPO is not built yet).
+
+Data parallel: environments are sharded over ranks; per update one all-reduce of the per-learner advantage moments
+``[G, 3]`` and per epoch one all-reduce of the flat gradient buffer ``[G, n_actor + n_critic (+ loss sums)]`` (RCCL)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, gmlp
+from .config import SCALED_ENV_CONFIG
+from .env import METRIC_KEYS
+from .env_scaled import PENDING_CAP, ScaledEdgeSimGym
+from .parallel import GradSync
+
+_STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tps", "load_balance_jain")
+
+
+def _stream(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class ScaledRolloutStorage:
+    """Device buffers of ``ems_rollout``."""
+
+    def __init__(self, n_envs, n_servers, n_deciders, horizon, device, capacity_entries=None):
+        B, S, D, T = int(n_envs), int(n_servers), int(n_deciders), int(horizon)
+        if capacity_entries is None:   # exact worst case for small batches, 4 acting deciders per env-step otherwise
+            worst = B * T * min(D, PENDING_CAP)
+            capacity_entries = worst if worst <= (1 << 22) else int(B * T * 4)
+        self.n_envs, self.n_servers, self.n_deciders, self.horizon, self.device = B, S, D, T, device
+        self.capacity_entries = E = int(capacity_entries)
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        self.t = dict(
+            ent_obs=z((E, S + 4), f32), ent_action=z((E, S + 1), f32), ent_logp=z(E, f32), ent_value=z(E, f32),
+            ent_env=z(E, i32), ent_agent=z(E, i32), ent_dst=z(E, i32), ent_adv=z(E, f32), ent_ret=z(E, f32),
+            reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), k_tb=z((T, B), u8), first_tb=z((T, B), i32),
+            counters=z(T + 1, torch.int64), group_off=z(D + 1, torch.int64), perm=z(B * PENDING_CAP, i32), err_flag=z(1, i32))
+        self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *[v.data_ptr() for v in self.t.values()])
+        self.steps_recorded = 0
+
+    def clear(self):
+        self.t["counters"].zero_()
+        self.t["k_tb"].zero_()
+        self.steps_recorded = 0
+
+    def total(self) -> int:
+        """Entries recorded so far; synchronises."""
+        if int(self.t["err_flag"].item()) != 0:
+            raise RuntimeError("rollout storage capacity exceeded; construct it with a larger capacity_entries")
+        return int(self.t["counters"][self.steps_recorded].item())
+
+
+class IPPO:
+    def __init__(self, n_servers, n_deciders, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2, value_loss_coeff=0.5,
+                 entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4, device="cuda:0", n_envs=1, horizon=1000,
+                 capacity_entries=None, seed=0, shared=False, process_group=None):
+        self.S, self.D = int(n_servers), int(n_deciders)
+        self.G = 1 if shared else self.D
+        self.gamma, self.gae_lambda, self.clip_param = gamma, gae_lambda, clip_param
+        self.value_loss_coeff, self.entropy_coeff = value_loss_coeff, entropy_coeff
+        self.max_grad_norm, self.num_sgd_iter, self.lr = max_grad_norm, num_sgd_iter, lr
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("marl_amd.IPPO runs on an MI355X (device='cuda:N'); there is no CPU path")
+        self._L = _lib.lib()
+        self.sync = GradSync(process_group)
+        self.actor = gmlp.GroupedMLP(self.G, self.S + 4, self.S + 1, True, self.device, seed=2 * seed)
+        self.critic = gmlp.GroupedMLP(self.G, self.S + 4, 1, False, self.device, seed=2 * seed + 1)
+        na, nc = self.actor.n_per, self.critic.n_per
+        # one gradient buffer for the data-parallel all-reduce: [G, actor | actor loss3 | critic | critic loss3]
+        self.grads = torch.zeros((self.G, na + 3 + nc + 3), dtype=torch.float32, device=self.device)
+        self.g_actor = torch.zeros((self.G, na), dtype=torch.float32, device=self.device)
+        self.g_critic = torch.zeros((self.G, nc), dtype=torch.float32, device=self.device)
+        self.l_actor = torch.zeros((self.G, 3), dtype=torch.float32, device=self.device)
+        self.l_critic = torch.zeros((self.G, 3), dtype=torch.float32, device=self.device)
+        self.m_a, self.v_a = torch.zeros_like(self.actor.flat), torch.zeros_like(self.actor.flat)
+        self.m_c, self.v_c = torch.zeros_like(self.critic.flat), torch.zeros_like(self.critic.flat)
+        self.step_count = 0
+        self.buffer = ScaledRolloutStorage(n_envs, self.S, self.D, horizon, self.device, capacity_entries)
+        self.moments = torch.zeros((self.G, 3), dtype=torch.float64, device=self.device)
+        self._chain = torch.zeros((int(n_envs), self.D, 2), dtype=torch.float64, device=self.device)
+        # workgroups per network: independent learners map one network per CU; a shared network uses the whole chip
+        self.split = 1 if self.G >= 64 else max(1, 256 // self.G)
+        self._slab_a = self._slab_c = None
+        self.last_update = {}
+
+    # -- rollout: MAPPOTrainer.train_episode steps 199-219 for all environments ----------------------------------------
+    def record_and_act(self, t, env: ScaledEdgeSimGym, placement, resource, explore=True, noise=None, seed=0, episode=0,
+                       env_offset=0, rng_step=None):
+        ro = self.buffer
+        tt = ro.t
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, self.G, env.n_pending.data_ptr(),
+                                                 env.pend_decider.data_ptr(), env.pend_obs.data_ptr(), _stream(self.device)),
+                       "ems_rollout_index")
+        gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
+                    tt["ent_action"], tt["ent_logp"], tt["group_off"], tt["perm"], self.split, noise=noise, explore=explore,
+                    seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
+        gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.split)
+        ro.steps_recorded = t + 1
+
+    # -- update ----------------------------------------------------------------------------------------------------------
+    def update(self):
+        ro = self.buffer
+        if ro.steps_recorded == 0:
+            return {}
+        E = ro.total()
+        if E == 0:
+            ro.clear()
+            return {}
+        tt, L, dev = ro.t, self._L, self.device
+        with torch.cuda.device(dev):
+            _lib.check(L.em_gae_agents(ro.n_envs, ro.steps_recorded, self.D, tt["reward_tb"].data_ptr(), tt["done_tb"].data_ptr(),
+                                       tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), tt["ent_agent"].data_ptr(),
+                                       tt["ent_value"].data_ptr(), float(self.gamma), float(self.gae_lambda),
+                                       self._chain.data_ptr(), tt["ent_adv"].data_ptr(), tt["ent_ret"].data_ptr(), _stream(dev)),
+                       "em_gae_agents")
+        x = tt["ent_obs"][:E]
+        if self.G > 1:
+            off, perm = gmlp.group_index(tt["ent_agent"][:E], self.G)      # stable: fixed summation order per learner
+        else:
+            off = torch.tensor([0, E], dtype=torch.int64, device=dev)
+            perm = None
+        gmlp.group_moments(tt["ent_adv"], off, perm, self.G, self.moments)
+        n_global = self._sum_moments()       # per-learner moments, summed over ranks
+        na, nc = self.actor.n_per, self.critic.n_per
+        sa, sc = self.actor.slab_floats(), self.critic.slab_floats()
+        rows = self.G * 4 * self.split
+        if self._slab_a is None:
+            self._slab_a = torch.empty(rows * sa, dtype=torch.float32, device=dev)
+            self._slab_c = torch.empty(rows * sc, dtype=torch.float32, device=dev)
+        acc = torch.zeros(6, dtype=torch.float64, device=dev)
+        for _ in range(int(self.num_sgd_iter)):
+            gmlp.actor_grad(self.actor, x, tt["ent_action"], tt["ent_logp"], tt["ent_adv"], self.moments, self.g_actor,
+                            self.l_actor, self._slab_a, off, perm, self.split, self.clip_param, self.entropy_coeff)
+            gmlp.critic_grad(self.critic, x, tt["ent_ret"], self.moments, self.g_critic, self.l_critic, self._slab_c, off, perm,
+                             self.split, self.value_loss_coeff)
+            if self.sync.enabled and self.sync.world_size > 1:   # the one data-path collective per epoch
+                g = self.grads
+                g[:, :na] = self.g_actor; g[:, na:na + 3] = self.l_actor
+                g[:, na + 3:na + 3 + nc] = self.g_critic; g[:, na + 3 + nc:] = self.l_critic
+                self.sync.sum_grads(g)
+                self.g_actor.copy_(g[:, :na]); self.l_actor.copy_(g[:, na:na + 3])
+                self.g_critic.copy_(g[:, na + 3:na + 3 + nc]); self.l_critic.copy_(g[:, na + 3 + nc:])
+            self.step_count += 1
+            gmlp.group_adam(self.actor.flat, self.g_actor, self.m_a, self.v_a, self.step_count, lr=self.lr,
+                            max_grad_norm=self.max_grad_norm)
+            gmlp.group_adam(self.critic.flat, self.g_critic, self.m_c, self.v_c, self.step_count, lr=self.lr,
+                            max_grad_norm=self.max_grad_norm)
+            acc[:3] += self.l_actor.sum(0).double()
+            acc[3:] += self.l_critic.sum(0).double()
+        ro.clear()
+        s = acc.cpu()
+        k = float(self.num_sgd_iter) * n_global
+        self.last_update = {"actor_loss": float(-s[0] / k), "critic_loss": float(0.5 * s[3] / k), "entropy": float(s[1] / k),
+                            "transitions": n_global}
+        return dict(self.last_update)
+
+    def _sum_moments(self) -> int:
+        if self.sync.enabled and self.sync.world_size > 1:
+            self.sync.dist.all_reduce(self.moments, op=self.sync.dist.ReduceOp.SUM, group=self.sync.group)
+        return int(round(float(self.moments[:, 0].sum().item())))
+
+    # -- checkpoint: flat parameter and Adam buffers --------------------------------------------------------------------
+    def save(self, path):
+        torch.save({"actor": self.actor.flat.cpu(), "critic": self.critic.flat.cpu(), "m_a": self.m_a.cpu(), "v_a": self.v_a.cpu(),
+                    "m_c": self.m_c.cpu(), "v_c": self.v_c.cpu(), "step": self.step_count,
+                    "shape": (self.S, self.D, self.G)}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        if tuple(ck["shape"]) != (self.S, self.D, self.G):
+            raise ValueError("checkpoint was written for another topology")
+        for dst, key in ((self.actor.flat, "actor"), (self.critic.flat, "critic"), (self.m_a, "m_a"), (self.v_a, "v_a"),
+                         (self.m_c, "m_c"), (self.v_c, "v_c")):
+            dst.copy_(ck[key].to(self.device))
+        self.step_count = int(ck["step"])
+
+
+class IPPOTrainer:
+    """The MAPPOTrainer interface (mappo_trainer.py:23-394: ``train_episode``, ``evaluate``, ``train``) for independent
+    learners on the scaled topology; one call of ``train_episode`` plays one episode in every environment."""
+
+    def __init__(self, env_config=None, seed=0, device="cuda:0", n_envs=1, rank=0, world_size=1, process_group=None,
+                 shared=False, capacity_entries=None, verbose=True):
+        self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
+        self.seed, self.n_envs, self.rank, self.world_size = int(seed), int(n_envs), int(rank), int(world_size)
+        cfg = dict(SCALED_ENV_CONFIG if env_config is None else env_config)
+        self.env_offset = self.rank * self.n_envs
+        self.env = ScaledEdgeSimGym(cfg, n_envs=self.n_envs, device=self.device, seed=self.seed, env_offset=self.env_offset,
+                                    latency_log_capacity=0)
+        self.S, self.D = self.env.n_nodes, self.env.n_deciders
+        self.algo = IPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
+                         capacity_entries=capacity_entries, seed=self.seed, shared=shared, process_group=process_group)
+        self.placement = torch.zeros((self.n_envs, PENDING_CAP), dtype=torch.int32, device=self.device)
+        self.resource = torch.full((self.n_envs, PENDING_CAP), 0.5, dtype=torch.float32, device=self.device)
+        self._train_storage = self.algo.buffer
+        self._scratch = None
+        self.policy_episode = 0
+        if verbose and self.rank == 0:
+            kind = "shared-parameter PPO" if shared else f"IPPO ({self.D} independent learners)"
+            print(f"[OK] {kind} (MI355X) initialised: {self.S} servers, {self.D} deciders, envs/GPU {self.n_envs}")
+
+    def train_episode(self, explore=True, record_buffer=True, noise=None):
+        env, a = self.env, self.algo
+        T = env.episode_len
+        if record_buffer:
+            a.buffer = self._train_storage
+            a.buffer.clear()
+        else:
+            if self._scratch is None:
+                self._scratch = ScaledRolloutStorage(self.n_envs, self.S, self.D, 1, self.device,
+                                                     capacity_entries=self.n_envs * PENDING_CAP)
+            a.buffer = self._scratch
+        ro = a.buffer
+        env.reset()
+        self.policy_episode += 1
+        total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        try:
+            for t in range(T):
+                slot = t if record_buffer else 0
+                if not record_buffer:
+                    ro.t["counters"].zero_()
+                a.record_and_act(slot, env, self.placement, self.resource, explore=explore, noise=noise, seed=self.seed,
+                                 episode=self.policy_episode, env_offset=self.env_offset, rng_step=t)
+                if record_buffer:
+                    env.step(self.placement, self.resource, by_slot=True, reward_seen_out=ro.t["reward_tb"][slot],
+                             done_out=ro.t["done_tb"][slot])
+                else:
+                    env.step(self.placement, self.resource, by_slot=True)
+                    total_reward += env.reward
+        finally:
+            a.buffer = self._train_storage
+        if record_buffer:
+            total_reward = ro.t["reward_tb"][:T].sum(dim=0)
+        metrics = env.episode_metrics()
+        has_final = (env.n_pending > 0).to(torch.float64).unsqueeze(1)      # mappo_trainer.py:222-231
+        per_env = torch.nan_to_num(metrics, nan=0.0) * has_final
+        mean = per_env.mean(dim=0).cpu().numpy()
+        idx = {k: i for i, k in enumerate(METRIC_KEYS)}
+        stats = {"episode_reward": float(total_reward.mean().item()), "episode_steps": T}
+        for k in _STAT_KEYS:
+            stats[k] = float(mean[idx[k]])
+        stats["per_env"] = {"episode_reward": total_reward, "metrics": metrics}
+        return stats
+
+    def evaluate(self, num_episodes=100):
+        prev = self.env.disable_env_exploration
+        self.env.disable_env_exploration = True
+        acc = {k: [] for k in _STAT_KEYS}
+        try:
+            for _ in range(max(1, -(-int(num_episodes) // self.n_envs))):
+                stats = self.train_episode(explore=False, record_buffer=False)
+                for k in _STAT_KEYS:
+                    acc[k].append(stats[k])
+        finally:
+            self.env.disable_env_exploration = prev
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+    def train(self, num_iterations=10, eval_interval=10, eval_episodes=10):
+        log = []
+        for it in range(1, num_iterations + 1):
+            st = self.train_episode(explore=True, record_buffer=True)
+            up = self.algo.update()
+            entry = {"algorithm": "IPPO", "seed": self.seed, "iteration": it, "episode_return_mean": st["episode_reward"], **up}
+            if it % eval_interval == 0:
+                entry.update(self.evaluate(eval_episodes))
+            log.append(entry)
+        return log

@@ -1,0 +1,123 @@
+"""End-to-end check of the scaled-topology trainers (marl_amd/ippo.py): rollout indexing, per-agent policy and critic,
+action scatter into the environment's slot arrays, reward rows, per-agent GAE and the grouped update, replayed against
+the numpy environment restatement and the torch-CPU restatement of the per-agent PPO arithmetic (oracle/ippo_oracle.py).
+
+The environment side is bit-exact; policy outputs 1e-5 relative; parameters after the update 1e-4 relative / 2e-6
+absolute (lr*m/(sqrt(v)+eps) amplifies last-bit gradient differences, as in tests/test_mappo_gpu.py).  Parity with the
+reference itself is unpinned for independent PPO (RLlib not vendored)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import edge_env_oracle as eo
+from oracle import ippo_oracle as io
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(T):
+    cfg = eo.default_config()
+    cfg.update(n_nodes=6, n_deciders=14, node_cpu_capacity=np.linspace(1.0, 3.0, 6) * 1e9, task_arrival_rate_range=(50, 150),
+               episode_length=T, disable_env_exploration=False)
+    cfg["exploration_schedule"] = {"initial_epsilon": 0.5, "final_epsilon": 0.05, "decay_steps": 40}
+    return cfg
+
+
+def _params_close(got, want, lr=3e-4, steps=2):
+    """1e-4 relative / 2e-6 absolute, except that a parameter whose gradient is ~1e-8 (Adam's eps) may move by a
+    different fraction of lr per step: such outliers must stay below 1e-4 of the entries and within lr * steps."""
+    d = np.abs(got - want)
+    bad = d > 2e-6 + 1e-4 * np.abs(want)
+    assert bad.mean() < 1e-4, bad.sum()
+    assert d.max() <= lr * steps, d.max()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_episode_and_update_match_restatement(shared):
+    from marl_amd.ippo import IPPOTrainer
+    T, B, seed = 30, 5, 17
+    cfg = _cfg(T)
+    S, D = cfg["n_nodes"], cfg["n_deciders"]
+    tr = IPPOTrainer(cfg, seed=seed, device="cuda:0", n_envs=B, shared=shared, verbose=False)
+    tr.algo.num_sgd_iter = 2
+    G = tr.algo.G
+    o, n = tr.algo.actor.offsets["log_std"]
+    tr.algo.actor.flat[:, o:o + n] = -0.5
+    flat_a0, flat_c0 = tr.algo.actor.flat.cpu().clone(), tr.algo.critic.flat.cpu().clone()
+    gen = torch.Generator().manual_seed(5)
+    noise = torch.randn((tr.algo.buffer.capacity_entries, S + 1), generator=gen)
+    tr.train_episode(explore=True, record_buffer=True, noise=noise.to("cuda:0").contiguous())
+    ro = tr.algo.buffer
+    E = ro.total()
+    t = {k: v.cpu() for k, v in ro.t.items()}
+    assert E > T          # the scenario produces work
+
+    # ---- replay: numpy environments driven by the actions the device recorded ---------------------------------------
+    envs = [eo.EdgeEnvOracle(cfg, eo.PhiloxDraws(seed, b, 1)) for b in range(B)]
+    obs = [e.reset()[0] for e in envs]
+    e_i = 0
+    for step in range(T):
+        for b, env in enumerate(envs):
+            order = list(env.pending.keys())
+            assert int(t["k_tb"][step, b]) == len(order) and (not order or int(t["first_tb"][step, b]) == e_i)
+            pl, rs = np.full(D, -1, np.int64), np.zeros(D, np.float32)
+            for k, d in enumerate(order):
+                assert int(t["ent_env"][e_i]) == b and int(t["ent_agent"][e_i]) == d and int(t["ent_dst"][e_i]) == b * 64 + k
+                assert np.array_equal(t["ent_obs"][e_i].numpy(), obs[b][d])
+                p, r = io.format_actions(t["ent_action"][e_i:e_i + 1], S)
+                pl[d], rs[d] = int(p[0]), float(r[0])
+                e_i += 1
+            out = env.step(pl, rs)
+            obs[b] = out.obs
+            assert float(t["reward_tb"][step, b]) == (out.reward if out.reward_emitted else 0.0)
+            assert int(t["done_tb"][step, b]) == int(out.done)
+    assert e_i == E
+
+    # ---- policy and critic outputs of the recorded entries -------------------------------------------------------------
+    agent = t["ent_agent"][:E].long() if not shared else torch.zeros(E, dtype=torch.int64)
+    x = t["ent_obs"][:E]
+    mu = io.forward(flat_a0, S + 4, S + 1, True, x, agent)
+    ls = torch.full((E, S + 1), -0.5)
+    a, lp = io.sample(mu, ls, noise[:E])
+    np.testing.assert_allclose(t["ent_action"][:E].numpy(), a.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(t["ent_logp"][:E].numpy(), lp.numpy(), rtol=2e-5, atol=2e-4)
+    v = io.forward(flat_c0, S + 4, 1, False, x, agent).squeeze(-1) * np.sqrt(1 + 1e-8)
+    np.testing.assert_allclose(t["ent_value"][:E].numpy(), v.numpy(), rtol=1e-5, atol=1e-5)
+
+    # ---- update: GAE chains, per-learner normalisation, two epochs ---------------------------------------------------------
+    stats = tr.algo.update()
+    adv, ret = io.gae_agents(t["reward_tb"].numpy(), t["done_tb"].numpy(), t["k_tb"].numpy(), t["first_tb"].numpy(),
+                             t["ent_agent"].numpy(), t["ent_value"].numpy())
+    assert np.array_equal(ro.t["ent_adv"][:E].cpu().numpy(), adv[:E]) and np.array_equal(ro.t["ent_ret"][:E].cpu().numpy(), ret[:E])
+    fa, fc = flat_a0.clone(), flat_c0.clone()
+    ma, va, mc, vc = (torch.zeros_like(fa), torch.zeros_like(fa), torch.zeros_like(fc), torch.zeros_like(fc))
+    adv_t, ret_t = torch.as_tensor(adv[:E]), torch.as_tensor(ret[:E])
+    sums = np.zeros(2)
+    for step in (1, 2):
+        ga, la = io.actor_grads(fa, S + 4, S + 1, x, t["ent_action"][:E], t["ent_logp"][:E], adv_t, agent)
+        gc, lc = io.critic_grads(fc, S + 4, x, ret_t, agent)
+        io.clip_adam(fa, ga, ma, va, step)
+        io.clip_adam(fc, gc, mc, vc, step)
+        sums += [la[:, 0].sum().item(), lc[:, 0].sum().item()]
+    _params_close(tr.algo.actor.flat.cpu().numpy(), fa.numpy())
+    _params_close(tr.algo.critic.flat.cpu().numpy(), fc.numpy())
+    assert stats["transitions"] == E
+    np.testing.assert_allclose(stats["actor_loss"], -sums[0] / (2 * E), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(stats["critic_loss"], 0.5 * sums[1] / (2 * E), rtol=1e-4)
+
+
+def test_scaled_64x256_smoke_and_eval():
+    """The configs[4] topology end to end: one recorded episode + update, then a deterministic evaluation episode."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 25
+    tr = IPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=96, verbose=False)
+    before = tr.algo.actor.flat.clone()
+    st = tr.train_episode()
+    up = tr.algo.update()
+    assert np.isfinite(st["episode_reward"]) and st["episode_reward"] < 0
+    assert up["transitions"] > 96 * 25 and np.isfinite(up["actor_loss"]) and np.isfinite(up["critic_loss"])
+    assert bool(torch.isfinite(tr.algo.actor.flat).all()) and not torch.equal(before, tr.algo.actor.flat)
+    ev = tr.evaluate(num_episodes=96)
+    assert all(np.isfinite(v) for v in ev.values())
