@@ -143,6 +143,57 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 
+def ippo_leg(device, rank, world, n_envs=4096, iters=2):
+    """configs[4]: independent PPO on the scaled topology (64 servers x 256 deciders, 10x arrival rate), n_envs
+    environments per GPU; one iteration = 1000-step rollout (256 per-agent actors and critics) + per-agent GAE + 4 PPO
+    epochs; data parallel over the ranks (one all-reduce of the [256, 21.5k] gradient buffer per epoch)."""
+    import torch.distributed as dist
+    from marl_amd.ippo import IPPOTrainer
+    tr = IPPOTrainer(None, seed=0, device=device, n_envs=n_envs, rank=rank, world_size=world, verbose=False)
+    T = tr.env.episode_len
+
+    def iteration():
+        t0 = time.perf_counter()
+        tr.train_episode(explore=True, record_buffer=True)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        out = tr.algo.update()
+        torch.cuda.synchronize(device)
+        return out.get("transitions", 0), t1 - t0, time.perf_counter() - t1
+
+    iteration()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    entries, roll, upd = 0, 0.0, 0.0
+    for _ in range(iters):
+        e, r, u = iteration()
+        entries += e            # already global (moments are all-reduced)
+        roll += r
+        upd += u
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tr.env.close()
+    if rank != 0:
+        return None
+    return {"metric": "IPPO samples/sec (scaled topology: transitions through rollout + per-agent GAE + 4-epoch PPO update)",
+            "value": entries / elapsed, "unit": "transitions/s", "env_steps_per_s": world * n_envs * T * iters / elapsed,
+            "agent_steps_per_s": world * n_envs * T * tr.D * iters / elapsed, "n_envs_per_gpu": n_envs, "learners": tr.D,
+            "iterations": iters, "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters,
+            "update_s_rank0": upd / iters, "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
+            "parity": "unpinned vs the reference (RLlib IPPO not vendored); pinned to oracle/ippo_oracle.py",
+            "collective": "1 all-reduce of [256, 21,516] floats per epoch + [256, 3] doubles per update" if world > 1 else "none"}
+
+
 def _cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -371,8 +422,10 @@ def main():
         fused = fused_leg(device, rank, world, B)
         scaled = scaled_leg(device, rank, world)
     mappo = None
+    ippo = None
     if not args.no_mappo:
         mappo = mappo_leg(device, rank, world, args.mappo_envs)
+        ippo = ippo_leg(device, rank, world)
 
     if rank == 0:
         agent_steps = world * B * n * args.steps
@@ -418,6 +471,8 @@ def main():
             line["scaled_topology"] = scaled
         if mappo is not None:
             line["mappo"] = mappo
+        if ippo is not None:
+            line["ippo_scaled"] = ippo
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

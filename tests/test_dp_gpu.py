@@ -49,3 +49,43 @@ def test_two_ranks_match_one_process(tmp_path):
     from marl_amd.trainer import MAPPOTrainer
     single = _run(MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=B_TOTAL, verbose=False))
     np.testing.assert_allclose(p0, single, rtol=2e-4, atol=2e-6)
+
+
+# ---- independent PPO on the scaled topology (marl_amd/ippo.py) -------------------------------------------------------
+def _scaled_cfg():
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg.update(n_nodes=8, n_deciders=24, node_cpu_capacity=np.linspace(1.0, 3.0, 8) * 1e9, episode_length=40)
+    return cfg
+
+
+def _run_ippo(trainer):
+    for _ in range(UPDATES):
+        trainer.train_episode(explore=True, record_buffer=True)
+        trainer.algo.update()
+    return np.concatenate([trainer.algo.actor.flat.cpu().numpy().ravel(), trainer.algo.critic.flat.cpu().numpy().ravel()])
+
+
+def _ippo_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.ippo import IPPOTrainer
+    tr = IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL // world, rank=rank, world_size=world, verbose=False)
+    np.save(os.path.join(out_dir, f"ippo_{rank}.npy"), _run_ippo(tr))
+    dist.destroy_process_group()
+
+
+def test_ippo_two_ranks_match_one_process(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ippo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = (np.load(tmp_path / f"ippo_{r}.npy") for r in range(2))
+    assert np.array_equal(p0, p1)
+    from marl_amd.ippo import IPPOTrainer
+    single = _run_ippo(IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL, verbose=False))
+    d = np.abs(p0 - single)
+    # Adam turns a last-bit difference of a ~1e-8 gradient into a fraction of lr: bound the outliers (tests/test_ippo_gpu.py)
+    assert (d > 2e-6 + 2e-4 * np.abs(single)).mean() < 1e-4 and d.max() <= 3e-4 * 4 * UPDATES
