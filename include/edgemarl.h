@@ -228,9 +228,12 @@ typedef struct ems_rollout {
     uint8_t *k_tb;         /* [T][B] entries of the step                                              */
     int32_t *first_tb;     /* [T][B] first entry of the step                                          */
     int64_t *counters;     /* [T+1]  entry base of each step; element 0 zeroed by the caller          */
-    int64_t *group_off;    /* [n_deciders+1] of the CURRENT step: positions of each group in perm     */
+    int64_t *group_off;    /* [n_deciders+3] of the CURRENT step: positions of each group in perm, then
+                              the pair {0, entries of the step} (the step as one group)               */
     int32_t *perm;         /* [n_envs*EMS_PENDING_CAP] of the CURRENT step: position -> entry index   */
     int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller     */
+    int32_t *ent_state;    /* [E] state row of the entry = step * n_envs + env (central critic); may be NULL */
+    float *value_tb;       /* [T][B] central-critic value of the (step, env) state; may be NULL        */
 } ems_rollout;
 
 /* Records which deciders act at step t (the pending lists ems_reset/ems_step returned): numbers the entries, copies
@@ -403,6 +406,33 @@ int em_group_moments(const float *adv, const int64_t *group_off, const int32_t *
 int em_gae_agents(int64_t n_envs, int32_t horizon, int32_t n_agents, const double *reward_tb, const uint8_t *done_tb,
                   const uint8_t *k_tb, const int32_t *first_tb, const int32_t *ent_agent, const float *ent_value,
                   double gamma, double lam, double *chain_state, float *ent_adv, float *ent_ret, void *stream);
+
+/* MAPPO's central critic on the scaled topology (MAPPOCritic, mappo_algorithm.py:74-90, on the concatenated state of
+ * mappo_trainer.py:101-123): D*width -> 64 -> 64 -> 1 with the first layer evaluated sparsely over the deciders that
+ * hold a task (absent deciders are zero rows of the state).  Parameters in torch.nn.Linear layout; w1 is [64][ldw],
+ * decider d owns columns [d*width, (d+1)*width). */
+typedef struct em_central_critic {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    int32_t n_deciders, width, ldw, pad;
+} em_central_critic;
+
+/* MAPPO.get_values (mappo_algorithm.py:226-239) for n_states states: state s has k_arr[s] entries starting at entry
+ * first_arr[s]; group_off/perm group the entries by decider (ems_rollout_index with n_groups = n_deciders).
+ * partial = scratch [entries][64]; value_out[s] is written for states with at least one entry. */
+int em_cc_forward(const em_central_critic *net, const float *ent_obs, const int64_t *group_off, const int32_t *perm,
+                  int32_t split, float *partial, int64_t n_states, const uint8_t *k_arr, const int32_t *first_arr,
+                  float value_norm_mean, float value_norm_var, float *value_out, void *stream);
+/* Floats of the `slab` scratch em_cc_grad needs. */
+int64_t em_cc_scratch_floats(const em_central_critic *net, int32_t split, int64_t n_states);
+/* One epoch of the critic part of MAPPO.update (mappo_algorithm.py:303,312-314): value_loss_coeff * 0.5 * mean over the
+ * n_global transitions of (norm(v) - norm(return))^2, every state evaluated once and weighted by its transitions.
+ * grad_out = [w1 (64 x ldw) | b1 | w2 | b2 | w3 | b3], loss3_out = {sum e^2, 0, transitions}; dz = scratch
+ * [n_states][64], partial = scratch [entries][64]. */
+int em_cc_grad(const em_central_critic *net, const float *ent_obs, const int32_t *ent_state, const float *ent_ret,
+               const int64_t *group_off, const int32_t *perm, int32_t split, float *partial, int64_t n_states,
+               const uint8_t *k_arr, const int32_t *first_arr, int64_t n_global, float value_loss_coeff,
+               float value_norm_mean, float value_norm_var, float *dz, float *slab, float *grad_out, float *loss3_out,
+               void *stream);
 
 int em_abi_version(void);
 const char *em_last_error(void);

@@ -70,7 +70,12 @@ class EmsRollout(C.Structure):
                 ("horizon", C.c_int32), ("pad", C.c_int32)] + [
         (name, C.c_void_p) for name in (
             "ent_obs", "ent_action", "ent_logp", "ent_value", "ent_env", "ent_agent", "ent_dst", "ent_adv", "ent_ret",
-            "reward_tb", "done_tb", "k_tb", "first_tb", "counters", "group_off", "perm", "err_flag")]
+            "reward_tb", "done_tb", "k_tb", "first_tb", "counters", "group_off", "perm", "err_flag", "ent_state", "value_tb")]
+
+
+class EmCentralCritic(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
+                ("b3", C.c_void_p), ("n_deciders", C.c_int32), ("width", C.c_int32), ("ldw", C.c_int32), ("pad", C.c_int32)]
 
 
 _lib = None
@@ -147,6 +152,13 @@ def lib() -> C.CDLL:
     L.em_group_adam.argtypes = [vp, vp, vp, vp, i64, i64, f64, i64, f64, f64, f64, f64, vp, vp]
     L.em_group_moments.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.em_gae_agents.argtypes = [i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]
+    CC = C.POINTER(EmCentralCritic)
+    L.em_cc_forward.argtypes = [CC, vp, vp, vp, C.c_int32, vp, i64, vp, vp, f32, f32, vp, vp]
+    L.em_cc_scratch_floats.argtypes = [CC, C.c_int32, i64]
+    L.em_cc_scratch_floats.restype = i64
+    L.em_cc_grad.argtypes = [CC, vp, vp, vp, vp, vp, C.c_int32, vp, i64, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
+    L.em_cc_forward.restype = C.c_int
+    L.em_cc_grad.restype = C.c_int
     for name in ("em_gmlp_forward", "em_gmlp_policy", "em_gmlp_value", "em_gmlp_actor_grad", "em_gmlp_critic_grad",
                  "em_group_adam", "em_group_moments", "em_gae_agents"):
         getattr(L, name).restype = C.c_int

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(IDX_THREADS) void scaled_step_index_kernel(const em
         if (n_groups == 1) { ro.group_off[0] = 0; ro.group_off[1] = overflow ? 0 : total; }
     }
     if (overflow) {
-        for (int i = tid; i <= n_groups; i += IDX_THREADS) ro.group_off[i] = 0;
+        for (int i = tid; i <= n_groups + 2; i += IDX_THREADS) ro.group_off[i] = 0;
         return;
     }
     if (n_groups == 1) {                                  // one shared network: identity order
@@ -106,7 +106,11 @@ __global__ __launch_bounds__(IDX_THREADS) void scaled_step_index_kernel(const em
         hist[g] = grun;                                   // cursor
         grun += c;
     }
-    if (tid == 0) ro.group_off[n_groups] = total;
+    if (tid == 0) {
+        ro.group_off[n_groups] = total;
+        ro.group_off[n_groups + 1] = 0;       // {0, total}: the whole step as ONE group, for a shared network that runs
+        ro.group_off[n_groups + 2] = total;   // over the same permutation (any order of the step's entries serves it)
+    }
     __syncthreads();
 
     // ---- (3) positions: entry (first[b] + slot) goes to the next free position of its group ----------------------
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void scaled_step_gather_kernel(const ems_rollo
         ro.ent_env[f + lane] = (int32_t)b;
         ro.ent_agent[f + lane] = pend_decider[b * PCAP + lane];
         ro.ent_dst[f + lane] = (int32_t)(b * PCAP + lane);
+        if (ro.ent_state) ro.ent_state[f + lane] = (int32_t)((int64_t)t * ro.n_envs + b);
     }
 }
 

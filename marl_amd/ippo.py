@@ -36,7 +36,7 @@ def _stream(device) -> int:
 class ScaledRolloutStorage:
     """Device buffers of ``ems_rollout``."""
 
-    def __init__(self, n_envs, n_servers, n_deciders, horizon, device, capacity_entries=None):
+    def __init__(self, n_envs, n_servers, n_deciders, horizon, device, capacity_entries=None, central=False):
         B, S, D, T = int(n_envs), int(n_servers), int(n_deciders), int(horizon)
         if capacity_entries is None:   # exact worst case for small batches, 4 acting deciders per env-step otherwise
             worst = B * T * min(D, PENDING_CAP)
@@ -49,8 +49,11 @@ class ScaledRolloutStorage:
             ent_obs=z((E, S + 4), f32), ent_action=z((E, S + 1), f32), ent_logp=z(E, f32), ent_value=z(E, f32),
             ent_env=z(E, i32), ent_agent=z(E, i32), ent_dst=z(E, i32), ent_adv=z(E, f32), ent_ret=z(E, f32),
             reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), k_tb=z((T, B), u8), first_tb=z((T, B), i32),
-            counters=z(T + 1, torch.int64), group_off=z(D + 1, torch.int64), perm=z(B * PENDING_CAP, i32), err_flag=z(1, i32))
-        self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *[v.data_ptr() for v in self.t.values()])
+            counters=z(T + 1, torch.int64), group_off=z(D + 3, torch.int64), perm=z(B * PENDING_CAP, i32), err_flag=z(1, i32))
+        if central:        # MAPPO's central critic: state row of every entry and dense per-(step, env) values
+            self.t.update(ent_state=z(E, i32), value_tb=z((T, B), f32))
+        ptrs = [v.data_ptr() for v in self.t.values()] + ([] if central else [None, None])
+        self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *ptrs)
         self.steps_recorded = 0
 
     def clear(self):
@@ -197,7 +200,11 @@ class IPPOTrainer:
     learners on the scaled topology; one call of ``train_episode`` plays one episode in every environment."""
 
     def __init__(self, env_config=None, seed=0, device="cuda:0", n_envs=1, rank=0, world_size=1, process_group=None,
-                 shared=False, capacity_entries=None, verbose=True):
+                 shared=False, capacity_entries=None, verbose=True, algorithm="ippo"):
+        """``algorithm``: "ippo" (one actor and one local critic per decider), "shared" (= ``shared=True``: one actor and one
+        local critic for all deciders) or "mappo" (shared actor + central critic, marl_amd/mappo_scaled.py)."""
+        if shared:
+            algorithm = "shared"
         self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
         self.seed, self.n_envs, self.rank, self.world_size = int(seed), int(n_envs), int(rank), int(world_size)
         cfg = dict(SCALED_ENV_CONFIG if env_config is None else env_config)
@@ -205,15 +212,25 @@ class IPPOTrainer:
         self.env = ScaledEdgeSimGym(cfg, n_envs=self.n_envs, device=self.device, seed=self.seed, env_offset=self.env_offset,
                                     latency_log_capacity=0)
         self.S, self.D = self.env.n_nodes, self.env.n_deciders
-        self.algo = IPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
-                         capacity_entries=capacity_entries, seed=self.seed, shared=shared, process_group=process_group)
+        self.algorithm = algorithm
+        if algorithm == "mappo":
+            from .mappo_scaled import ScaledMAPPO
+            self.algo = ScaledMAPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
+                                    capacity_entries=capacity_entries, seed=self.seed, process_group=process_group)
+        elif algorithm in ("ippo", "shared"):
+            self.algo = IPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
+                             capacity_entries=capacity_entries, seed=self.seed, shared=algorithm == "shared",
+                             process_group=process_group)
+        else:
+            raise ValueError(f"unknown algorithm {algorithm!r}")
         self.placement = torch.zeros((self.n_envs, PENDING_CAP), dtype=torch.int32, device=self.device)
         self.resource = torch.full((self.n_envs, PENDING_CAP), 0.5, dtype=torch.float32, device=self.device)
         self._train_storage = self.algo.buffer
         self._scratch = None
         self.policy_episode = 0
         if verbose and self.rank == 0:
-            kind = "shared-parameter PPO" if shared else f"IPPO ({self.D} independent learners)"
+            kind = {"shared": "shared-parameter PPO", "mappo": "MAPPO (shared actor, central critic)"}.get(
+                algorithm, f"IPPO ({self.D} independent learners)")
             print(f"[OK] {kind} (MI355X) initialised: {self.S} servers, {self.D} deciders, envs/GPU {self.n_envs}")
 
     def train_episode(self, explore=True, record_buffer=True, noise=None):
@@ -225,7 +242,8 @@ class IPPOTrainer:
         else:
             if self._scratch is None:
                 self._scratch = ScaledRolloutStorage(self.n_envs, self.S, self.D, 1, self.device,
-                                                     capacity_entries=self.n_envs * PENDING_CAP)
+                                                     capacity_entries=self.n_envs * PENDING_CAP,
+                                                     central=self.algorithm == "mappo")
             a.buffer = self._scratch
         ro = a.buffer
         env.reset()
@@ -277,7 +295,7 @@ class IPPOTrainer:
         for it in range(1, num_iterations + 1):
             st = self.train_episode(explore=True, record_buffer=True)
             up = self.algo.update()
-            entry = {"algorithm": "IPPO", "seed": self.seed, "iteration": it, "episode_return_mean": st["episode_reward"], **up}
+            entry = {"algorithm": self.algorithm.upper(), "seed": self.seed, "iteration": it, "episode_return_mean": st["episode_reward"], **up}
             if it % eval_interval == 0:
                 entry.update(self.evaluate(eval_episodes))
             log.append(entry)
