@@ -8,8 +8,8 @@ decider owns an actor (S+4 -> 64 -> 64 -> S+1, state-independent log_std) and a 
 formatting (``mappo_algorithm.py:62-71``, ``mappo_trainer.py:125-158``), GAE (``:241-262``) over the agent's own chain per
 environment, advantage normalisation over the learner's batch (``:293``), PPO-clip / value / entropy losses
 (``:302-320``), separate gradient clipping and Adam per network (``:328-332``).  ``shared=True`` replaces the 256 networks
-by one actor and one local critic shared by all deciders (parameter sharing; the central 17,408-wide critic of a
-scaled MAPPO is not built yet).
+by one actor and one local critic shared by all deciders (parameter sharing); MAPPO proper (shared actor + central
+17,408-wide critic) is ``marl_amd/mappo_scaled.py``, reached through ``IPPOTrainer(algorithm="mappo")``.
 
 Data parallel: environments are sharded over ranks; per update one all-reduce of the per-learner advantage moments
 ``[G, 3]`` and per epoch one all-reduce of the flat gradient buffer ``[G, n_actor + n_critic (+ loss sums)]`` (RCCL)."""

@@ -66,26 +66,28 @@ def _run_ippo(trainer):
     return np.concatenate([trainer.algo.actor.flat.cpu().numpy().ravel(), trainer.algo.critic.flat.cpu().numpy().ravel()])
 
 
-def _ippo_worker(rank, world, port, out_dir):
+def _ippo_worker(rank, world, port, out_dir, algorithm="ippo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from marl_amd.ippo import IPPOTrainer
-    tr = IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL // world, rank=rank, world_size=world, verbose=False)
+    tr = IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL // world, rank=rank, world_size=world, verbose=False,
+                     algorithm=algorithm)
     np.save(os.path.join(out_dir, f"ippo_{rank}.npy"), _run_ippo(tr))
     dist.destroy_process_group()
 
 
-def test_ippo_two_ranks_match_one_process(tmp_path):
+@pytest.mark.parametrize("algorithm", ["ippo", "mappo"])
+def test_ippo_two_ranks_match_one_process(tmp_path, algorithm):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_ippo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_ippo_worker, args=(2, port, str(tmp_path), algorithm), nprocs=2, join=True)
     p0, p1 = (np.load(tmp_path / f"ippo_{r}.npy") for r in range(2))
     assert np.array_equal(p0, p1)
     from marl_amd.ippo import IPPOTrainer
-    single = _run_ippo(IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL, verbose=False))
+    single = _run_ippo(IPPOTrainer(_scaled_cfg(), seed=5, device="cuda:0", n_envs=B_TOTAL, verbose=False, algorithm=algorithm))
     d = np.abs(p0 - single)
     # Adam turns a last-bit difference of a ~1e-8 gradient into a fraction of lr: bound the outliers (tests/test_ippo_gpu.py)
     assert (d > 2e-6 + 2e-4 * np.abs(single)).mean() < 1e-4 and d.max() <= 3e-4 * 4 * UPDATES
