@@ -234,6 +234,7 @@ typedef struct ems_rollout {
     int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller     */
     int32_t *ent_state;    /* [E] state row of the entry = step * n_envs + env (central critic); may be NULL */
     float *value_tb;       /* [T][B] central-critic value of the (step, env) state; may be NULL        */
+    int32_t *index_scratch; /* [ceil(B/256) + 2*n_deciders + 1] scratch of ems_rollout_index, zeroed by the caller once */
 } ems_rollout;
 
 /* Records which deciders act at step t (the pending lists ems_reset/ems_step returned): numbers the entries, copies

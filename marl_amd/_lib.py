@@ -70,7 +70,7 @@ class EmsRollout(C.Structure):
                 ("horizon", C.c_int32), ("pad", C.c_int32)] + [
         (name, C.c_void_p) for name in (
             "ent_obs", "ent_action", "ent_logp", "ent_value", "ent_env", "ent_agent", "ent_dst", "ent_adv", "ent_ret",
-            "reward_tb", "done_tb", "k_tb", "first_tb", "counters", "group_off", "perm", "err_flag", "ent_state", "value_tb")]
+            "reward_tb", "done_tb", "k_tb", "first_tb", "counters", "group_off", "perm", "err_flag", "ent_state", "value_tb", "index_scratch")]
 
 
 class EmCentralCritic(C.Structure):

@@ -5,9 +5,11 @@
 // exclusive scan of the per-environment pending counts; (2) the step's entries are grouped by the network that
 // serves them (decider id for independent learners, one group for a shared network) with a counting sort, which gives
 // the group offsets and the position -> entry permutation the grouped MLP kernels (gmlp.hip) consume; (3) the
-// observation rows are copied into the entry storage.  (1)+(2) run in ONE workgroup (the work is a few items per
-// environment), (3) is a wide copy kernel.  The order inside a group comes from LDS atomics and may vary from run to
-// run: the rollout forward treats rows independently, so results do not depend on it (the update sorts stably).
+// observation rows are copied into the entry storage.  Three short launches: a chunk-parallel count (scan inside
+// 256-environment chunks + histogram), a single-workgroup scan of the chunk totals and of the histogram, and a
+// wavefront-per-environment placement + copy.  The order inside a group comes from integer atomics and may vary from run
+// to run: the rollout forward treats rows independently, so results do not depend on it (the update sorts stably).
+// (A single-workgroup version of (1)+(2) cost 29 us per step at 4,096 environments and 117 us at 16,384.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -19,130 +21,143 @@
 namespace {
 
 constexpr int PCAP = EMS_PENDING_CAP;
-constexpr int IDX_THREADS = 1024;
+constexpr int CHUNK = 256;            // environments per workgroup of the count kernel
 
-__global__ __launch_bounds__(IDX_THREADS) void scaled_step_index_kernel(const ems_rollout ro, int t, int n_groups,
-                                                                        const int32_t* __restrict__ n_pending,
-                                                                        const int32_t* __restrict__ pend_decider)
+// (1) per 256-environment chunk: entries per environment, exclusive scan inside the chunk, chunk total, and the chunk's
+// contribution to the per-group histogram (LDS histogram, flushed with integer atomics: exact in any order).
+__global__ __launch_bounds__(CHUNK) void scaled_index_count_kernel(const ems_rollout ro, int t, int n_groups,
+                                                                   const int32_t* __restrict__ n_pending,
+                                                                   const int32_t* __restrict__ pend_decider,
+                                                                   int32_t* __restrict__ chunk_tot, int32_t* __restrict__ hist)
 {
-    extern __shared__ int32_t sm[];
-    int32_t* hist = sm;                       // [n_groups] counts, then running cursors
-    int32_t* part = sm + n_groups;            // [IDX_THREADS] partial sums
-    const int tid = threadIdx.x;
-    const int64_t B = ro.n_envs;
-    const int64_t base = ro.counters[t];
-    for (int i = tid; i < n_groups; i += IDX_THREADS) hist[i] = 0;
+    extern __shared__ int32_t lh[];               // [n_groups] when grouping
+    __shared__ int32_t wsum[CHUNK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t B = ro.n_envs, b = (int64_t)blockIdx.x * CHUNK + tid;
+    if (n_groups > 1) {
+        for (int i = tid; i < n_groups; i += CHUNK) lh[i] = 0;
+        __syncthreads();
+    }
+    int k = b < B ? n_pending[b] : 0;
+    k = k < 0 ? 0 : (k > PCAP ? PCAP : k);
+    if (n_groups > 1)
+        for (int j = 0; j < k; ++j) atomicAdd(&lh[pend_decider[b * PCAP + j]], 1);
+    int inc = k;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CHUNK / 64; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+    if (b < B) {
+        ro.k_tb[(int64_t)t * B + b] = (uint8_t)k;
+        ro.first_tb[(int64_t)t * B + b] = woff + inc - k;        // offset inside the chunk; the place kernel adds the bases
+    }
+    if (tid == 0) chunk_tot[blockIdx.x] = tot;
+    if (n_groups > 1)
+        for (int i = tid; i < n_groups; i += CHUNK) { const int c = lh[i]; if (c) atomicAdd(&hist[i], c); }
+}
 
-    // ---- (1) entries per environment: chunked exclusive scan; group histogram on the way ---------------------
-    const int64_t chunk = (B + IDX_THREADS - 1) / IDX_THREADS;
-    const int64_t b0 = (int64_t)tid * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
-    int32_t local = 0;
-    for (int64_t b = b0; b < b1; ++b) {
-        int k = n_pending[b];
-        k = k < 0 ? 0 : (k > PCAP ? PCAP : k);
-        local += k;
-        if (n_groups > 1)
-            for (int j = 0; j < k; ++j) atomicAdd(&hist[pend_decider[b * PCAP + j]], 1);
-    }
-    part[tid] = local;
+// (2) one workgroup: chunk bases, the step's total, capacity check, group offsets and cursors; re-zeroes the histogram
+__global__ __launch_bounds__(256) void scaled_index_scan_kernel(const ems_rollout ro, int t, int n_groups, int n_chunks,
+                                                                int32_t* __restrict__ chunk_tot, int32_t* __restrict__ hist,
+                                                                int32_t* __restrict__ cursor, int32_t* __restrict__ ok_flag)
+{
+    __shared__ int32_t part[256];
+    __shared__ int32_t s_total;
+    const int tid = threadIdx.x;
+    auto block_scan = [&](int32_t v) -> int32_t {          // inclusive scan of one value per thread
+        part[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int32_t o = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += o;
+            __syncthreads();
+        }
+        const int32_t r = part[tid];
+        __syncthreads();
+        return r;
+    };
+    // chunk totals -> exclusive bases (in place)
+    const int cper = (n_chunks + 255) / 256;
+    const int c0 = tid * cper, c1 = c0 + cper < n_chunks ? c0 + cper : n_chunks;
+    int32_t loc = 0;
+    for (int i = c0; i < c1; ++i) loc += chunk_tot[i];
+    int32_t run = block_scan(loc) - loc;
+    for (int i = c0; i < c1; ++i) { const int32_t v = chunk_tot[i]; chunk_tot[i] = run; run += v; }
+    if (tid == 255) s_total = run;
     __syncthreads();
-    for (int d = 1; d < IDX_THREADS; d <<= 1) {         // inclusive Hillis-Steele scan of the partial sums
-        const int32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const int32_t total = part[IDX_THREADS - 1];
+    const int32_t total = s_total;
+    const int64_t base = ro.counters[t];
     const bool overflow = base + total > ro.capacity_entries;
-    int32_t run = part[tid] - local;
-    uint8_t* k_row = ro.k_tb + (int64_t)t * B;
-    int32_t* f_row = ro.first_tb + (int64_t)t * B;
-    for (int64_t b = b0; b < b1; ++b) {
-        int k = n_pending[b];
-        k = k < 0 ? 0 : (k > PCAP ? PCAP : k);
-        k_row[b] = overflow ? 0 : (uint8_t)k;
-        f_row[b] = (int32_t)(base + run);
-        run += k;
-    }
     if (tid == 0) {
         if (overflow) atomicOr(ro.err_flag, 8);
         ro.counters[t + 1] = base + (overflow ? 0 : total);
-        if (n_groups == 1) { ro.group_off[0] = 0; ro.group_off[1] = overflow ? 0 : total; }
+        *ok_flag = overflow ? 0 : 1;
     }
-    if (overflow) {
-        for (int i = tid; i <= n_groups + 2; i += IDX_THREADS) ro.group_off[i] = 0;
+    const int32_t eff = overflow ? 0 : total;
+    if (n_groups == 1) {
+        if (tid == 0) { ro.group_off[0] = 0; ro.group_off[1] = eff; }
         return;
     }
-    if (n_groups == 1) {                                  // one shared network: identity order
-        run = part[tid] - local;
-        for (int64_t b = b0; b < b1; ++b) {
-            const int k = k_row[b];
-            for (int j = 0; j < k; ++j) ro.perm[run + j] = (int32_t)(base + run + j);
-            run += k;
-        }
-        return;
-    }
-    __syncthreads();
-
-    // ---- (2) exclusive scan of the histogram -> group offsets and cursors --------------------------------------
-    const int gchunk = (n_groups + IDX_THREADS - 1) / IDX_THREADS;
-    const int g0 = tid * gchunk, g1 = g0 + gchunk < n_groups ? g0 + gchunk : n_groups;
+    const int gper = (n_groups + 255) / 256;
+    const int g0 = tid * gper, g1 = g0 + gper < n_groups ? g0 + gper : n_groups;
     int32_t gl = 0;
     for (int g = g0; g < g1; ++g) gl += hist[g];
-    __syncthreads();
-    part[tid] = gl;
-    __syncthreads();
-    for (int d = 1; d < IDX_THREADS; d <<= 1) {
-        const int32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int32_t grun = part[tid] - gl;
+    int32_t grun = block_scan(gl) - gl;
     for (int g = g0; g < g1; ++g) {
         const int32_t c = hist[g];
-        ro.group_off[g] = grun;
-        hist[g] = grun;                                   // cursor
+        ro.group_off[g] = overflow ? 0 : grun;
+        cursor[g] = grun;
+        hist[g] = 0;                                           // ready for the next step
         grun += c;
     }
     if (tid == 0) {
-        ro.group_off[n_groups] = total;
-        ro.group_off[n_groups + 1] = 0;       // {0, total}: the whole step as ONE group, for a shared network that runs
-        ro.group_off[n_groups + 2] = total;   // over the same permutation (any order of the step's entries serves it)
-    }
-    __syncthreads();
-
-    // ---- (3) positions: entry (first[b] + slot) goes to the next free position of its group ----------------------
-    for (int64_t b = b0; b < b1; ++b) {
-        const int k = k_row[b];
-        const int32_t f = f_row[b];
-        for (int j = 0; j < k; ++j) {
-            const int pos = atomicAdd(&hist[pend_decider[b * PCAP + j]], 1);
-            ro.perm[pos] = f + j;
-        }
+        ro.group_off[n_groups] = eff;
+        ro.group_off[n_groups + 1] = 0;       // {0, total}: the step as ONE group, for a shared network that runs over
+        ro.group_off[n_groups + 2] = eff;     // the same permutation (any order of the step's entries serves it)
     }
 }
 
-// entry rows of step t: observation, environment, decider, destination slot of the action (env * 64 + slot)
-__global__ __launch_bounds__(256) void scaled_step_gather_kernel(const ems_rollout ro, int t, const int32_t* __restrict__ pend_decider,
-                                                                 const float* __restrict__ pend_obs)
+// (3) one wavefront per environment: final entry numbers, positions inside the groups (integer atomics on the
+// cursors: the order inside a group may vary, which cannot change a forward result), entry rows
+__global__ __launch_bounds__(256) void scaled_index_place_kernel(const ems_rollout ro, int t, int n_groups,
+                                                                 const int32_t* __restrict__ pend_decider,
+                                                                 const float* __restrict__ pend_obs,
+                                                                 const int32_t* __restrict__ chunk_base, int32_t* __restrict__ cursor,
+                                                                 const int32_t* __restrict__ ok_flag)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= ro.n_envs) return;
-    const int k = ro.k_tb[(int64_t)t * ro.n_envs + b];
+    const int64_t B = ro.n_envs, b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t base = ro.counters[t];
+    const int64_t i = (int64_t)t * B + b;
+    const int32_t rel = chunk_base[b / CHUNK] + ro.first_tb[i];          // position of the first entry inside the step
+    const int64_t f = base + rel;
+    int k = ro.k_tb[i];
+    if (*ok_flag == 0) {                                                  // capacity overflow: the step records nothing
+        if (lane == 0) { ro.k_tb[i] = 0; ro.first_tb[i] = (int32_t)base; }
+        return;
+    }
+    if (lane == 0) ro.first_tb[i] = (int32_t)f;
     if (k == 0) return;
-    const int64_t f = ro.first_tb[(int64_t)t * ro.n_envs + b];
     const int w = ro.n_servers + 4;
     const float* src = pend_obs + b * PCAP * (int64_t)w;
     float* dst = ro.ent_obs + f * w;
-    for (int i = lane; i < k * w; i += 64) dst[i] = src[i];      // k consecutive rows on both sides
+    for (int x = lane; x < k * w; x += 64) dst[x] = src[x];               // k consecutive rows on both sides
     if (lane < k) {
+        const int dec = pend_decider[b * PCAP + lane];
+        const int pos = n_groups > 1 ? atomicAdd(&cursor[dec], 1) : rel + lane;
+        ro.perm[pos] = (int32_t)(f + lane);
         ro.ent_env[f + lane] = (int32_t)b;
-        ro.ent_agent[f + lane] = pend_decider[b * PCAP + lane];
+        ro.ent_agent[f + lane] = dec;
         ro.ent_dst[f + lane] = (int32_t)(b * PCAP + lane);
-        if (ro.ent_state) ro.ent_state[f + lane] = (int32_t)((int64_t)t * ro.n_envs + b);
+        if (ro.ent_state) ro.ent_state[f + lane] = (int32_t)i;
     }
 }
 
@@ -160,11 +175,20 @@ int ems_rollout_index(const ems_rollout* ro, int32_t t, int32_t n_groups, const 
     if (!ro->ent_obs || !ro->ent_env || !ro->ent_agent || !ro->ent_dst || !ro->k_tb || !ro->first_tb || !ro->counters ||
         !ro->group_off || !ro->perm || !ro->err_flag)
         return em::fail(EM_ERR_INVALID, "ems_rollout_index: storage pointers missing");
+    if (!ro->index_scratch) return em::fail(EM_ERR_INVALID, "ems_rollout_index: index_scratch is required");
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = sizeof(int32_t) * ((size_t)n_groups + IDX_THREADS);
-    hipLaunchKernelGGL(scaled_step_index_kernel, dim3(1), dim3(IDX_THREADS), lds, s, *ro, t, n_groups, n_pending, pend_decider);
-    hipLaunchKernelGGL(scaled_step_gather_kernel, dim3((unsigned)((ro->n_envs + 3) / 4)), dim3(256), 0, s, *ro, t, pend_decider,
-                       pend_obs);
+    const int n_chunks = (int)((ro->n_envs + CHUNK - 1) / CHUNK);
+    // scratch: [n_chunks] chunk totals/bases | [n_deciders] histogram (zero between calls) | [n_deciders] cursors | ok flag
+    int32_t* chunk_tot = ro->index_scratch;
+    int32_t* hist = chunk_tot + n_chunks;
+    int32_t* cursor = hist + ro->n_deciders;
+    int32_t* ok_flag = cursor + ro->n_deciders;
+    const size_t lds = n_groups > 1 ? sizeof(int32_t) * (size_t)n_groups : 0;
+    hipLaunchKernelGGL(scaled_index_count_kernel, dim3((unsigned)n_chunks), dim3(CHUNK), lds, s, *ro, t, n_groups, n_pending,
+                       pend_decider, chunk_tot, hist);
+    hipLaunchKernelGGL(scaled_index_scan_kernel, dim3(1), dim3(256), 0, s, *ro, t, n_groups, n_chunks, chunk_tot, hist, cursor, ok_flag);
+    hipLaunchKernelGGL(scaled_index_place_kernel, dim3((unsigned)((ro->n_envs + 3) / 4)), dim3(256), 0, s, *ro, t, n_groups,
+                       pend_decider, pend_obs, chunk_tot, cursor, ok_flag);
     return em::hip_check(hipGetLastError(), "scaled rollout index launch");
 }
 

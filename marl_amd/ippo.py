@@ -53,7 +53,8 @@ class ScaledRolloutStorage:
         if central:        # MAPPO's central critic: state row of every entry and dense per-(step, env) values
             self.t.update(ent_state=z(E, i32), value_tb=z((T, B), f32))
         ptrs = [v.data_ptr() for v in self.t.values()] + ([] if central else [None, None])
-        self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *ptrs)
+        self.index_scratch = z((B + 255) // 256 + 2 * D + 1, i32)
+        self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *ptrs, self.index_scratch.data_ptr())
         self.steps_recorded = 0
 
     def clear(self):

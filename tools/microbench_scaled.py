@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from marl_amd.config import SCALED_ENV_CONFIG  # noqa: E402
 from marl_amd.env_scaled import PENDING_CAP, ScaledEdgeSimGym  # noqa: E402
 
