@@ -143,7 +143,7 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 
-def ippo_leg(device, rank, world, n_envs=4096, iters=2, algorithm="ippo"):
+def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
     """configs[4]: independent PPO on the scaled topology (64 servers x 256 deciders, 10x arrival rate), n_envs
     environments per GPU; one iteration = 1000-step rollout (256 per-agent actors and critics) + per-agent GAE + 4 PPO
     epochs; data parallel over the ranks (one all-reduce of the [256, 21.5k] gradient buffer per epoch)."""
@@ -419,7 +419,7 @@ def main():
 
     B = args.envs
     elapsed, dev_ms, n, T, record_bytes = time_env_steps(device, rank, world, B, args.steps, args.warmup)
-    wg_waves = 8
+    wg_waves = 5 if B < 65536 else 8          # the library's automatic choice (em_set_workgroup_waves)
     scale = None
     if not args.no_scale_point and B != 65536:
         # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)

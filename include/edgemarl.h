@@ -156,7 +156,8 @@ int64_t em_n_envs(const em_handle *h);
  * 65,536 environments or more when it fits more environments per wavefront).  Results do not depend on it. */
 int em_set_lanes_per_env(em_handle *h, int lanes);
 /* Kernel variant: wavefronts per workgroup of the reset/step kernel (waves - 1 worker wavefronts and one
- * scalar wavefront, 2..8); 0 restores the default.  Results do not depend on it. */
+ * scalar wavefront, 2..8); 0 restores the automatic choice (5 below 65,536 environments, 8 from there on).  Results
+ * do not depend on it. */
 int em_set_workgroup_waves(em_handle *h, int waves);
 
 

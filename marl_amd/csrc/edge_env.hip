@@ -1368,6 +1368,11 @@ int pick_lanes(int n, int64_t n_envs)
     return p2;
 }
 
+// Wavefronts per workgroup (workers + 1 scalar).  Small batches are bound by the critical path of ONE workgroup, where
+// the workers' barrier wait grows with their number: 4 workers + 1 scalar measured best up to 16,384 environments
+// (6.98 vs 7.43 us per launch at 4,096), 7 + 1 amortises the scalar wavefront best at 65,536 and above.
+int pick_waves(int64_t n_envs) { return n_envs < EM_PACKED_MIN_ENVS ? 5 : 8; }
+
 EnvParams make_params(const em_handle* h, int lanes)
 {
     const em_config& c = h->cfg;
@@ -1532,6 +1537,7 @@ int em_create(const em_config* cfg, int64_t n_envs, int device_id, uint64_t seed
     h->explore_off = cfg->disable_env_exploration;
     h->lat_cap = latency_log_capacity;
     h->lanes = pick_lanes(cfg->n_nodes, n_envs);
+    h->wg_waves = pick_waves(n_envs);
     const size_t sbytes = (size_t)n_envs * rec_bytes(cfg->n_nodes);
     hipError_t e = hipMalloc(&h->d_state, sbytes);
     if (e == hipSuccess) e = hipMemset(h->d_state, 0, sbytes);
@@ -1696,7 +1702,7 @@ int em_set_lanes_per_env(em_handle* h, int lanes)
 int em_set_workgroup_waves(em_handle* h, int waves)
 {
     if (!h) return em::fail(EM_ERR_INVALID, "null handle");
-    if (waves == 0) waves = 8;
+    if (waves == 0) waves = pick_waves(h->n_envs);
     if (waves < 2 || waves * 64 > EM_ENV_MAX_THREADS) return em::fail(EM_ERR_INVALID, "workgroup wavefronts must be 2..%d", EM_ENV_MAX_THREADS / 64);
     h->wg_waves = waves;
     return EM_OK;
