@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
     L.ems_get_state.argtypes = [vp] + [vp] * 7
     L.ems_rollout_index.argtypes = [C.POINTER(EmsRollout), C.c_int32, C.c_int32, vp, vp, vp, vp]
     L.ems_rollout_index.restype = C.c_int
+    L.ems_set_envs_per_wave.argtypes = [vp, i32]
+    L.ems_set_envs_per_wave.restype = C.c_int
     L.ems_record_bytes.argtypes = [vp]
     L.ems_record_bytes.restype = i64
     for name in ("ems_create", "ems_destroy", "ems_reset", "ems_step", "ems_episode_metrics", "ems_set_exploration",

@@ -98,6 +98,10 @@ class ScaledEdgeSimGym:
     def global_step_counter(self, v: int):
         _lib.check(self._L.ems_set_exploration(self._h, int(self._disable_env_exploration), int(v)))
 
+    def set_envs_per_wave(self, envs_per_wave: int):
+        """Kernel variant (4 environments per wavefront by default, or 1); tuning/tests only, identical results."""
+        _lib.check(self._L.ems_set_envs_per_wave(self._h, int(envs_per_wave)))
+
     @property
     def record_bytes(self) -> int:
         return int(self._L.ems_record_bytes(self._h))

@@ -44,7 +44,7 @@ def _check_lists(env, refs, outs, t):
             assert np.array_equal(obs[b, k], r_obs[d]), (t, b, k, d)
 
 
-def _run_against_numpy(cfg, B, T, explore, by_slot=False, episodes=1):
+def _run_against_numpy(cfg, B, T, explore, by_slot=False, episodes=1, epw=0):
     from marl_amd.env_scaled import ScaledEdgeSimGym, PENDING_CAP
     cfg = dict(cfg)
     cfg.update(episode_length=T, disable_env_exploration=not explore)
@@ -52,6 +52,7 @@ def _run_against_numpy(cfg, B, T, explore, by_slot=False, episodes=1):
     S, D, off = cfg["n_nodes"], cfg["n_deciders"], 700
     env = ScaledEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=SEED, env_offset=off, latency_log_capacity=64 * T)
     env.enable_debug_outputs()
+    env.set_envs_per_wave(epw or 4)     # small test batches would pick one environment per wavefront automatically
     counter = 0
     for episode in range(1, episodes + 1):
         refs = _oracles(cfg, B, off, episode)
@@ -99,9 +100,10 @@ def _run_against_numpy(cfg, B, T, explore, by_slot=False, episodes=1):
     env.close()
 
 
+@pytest.mark.parametrize("epw", [4, 1])
 @pytest.mark.parametrize("explore", [False, True])
-def test_scaled_64x256_matches_numpy_restatement(explore):
-    _run_against_numpy(scaled_cfg(), B=9, T=120, explore=explore, episodes=2 if explore else 1)
+def test_scaled_64x256_matches_numpy_restatement(explore, epw):
+    _run_against_numpy(scaled_cfg(), B=9, T=120, explore=explore, episodes=2 if explore else 1, epw=epw)
 
 
 def test_scaled_actions_by_slot():
@@ -113,7 +115,8 @@ def test_shared_home_servers_and_duplicate_arrivals():
     decider's duplicate just bumped (the case D == S never produces)."""
     cfg = scaled_cfg(n_nodes=4, n_deciders=12, node_cpu_capacity=np.array([1.0, 1.7, 2.2, 3.0]) * 1e9,
                      task_arrival_rate_range=(200, 600), task_arrival_mode="random")
-    _run_against_numpy(cfg, B=7, T=150, explore=False)
+    _run_against_numpy(cfg, B=7, T=150, explore=False)      # mixes 16-lane groups and the general path inside a wavefront
+    _run_against_numpy(cfg, B=7, T=60, explore=True, epw=1)
 
 
 def test_more_than_64_arrivals_per_step():
@@ -136,6 +139,7 @@ def test_reduces_to_the_reference_step_at_d_equals_s(explore):
     cfg["exploration_schedule"] = {"initial_epsilon": 1.0, "final_epsilon": 0.05, "decay_steps": 150}
     a = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=SEED, env_offset=31, latency_log_capacity=T * n)
     b = ScaledEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=SEED, env_offset=31, latency_log_capacity=T * n)
+    b.set_envs_per_wave(4 if explore else 1)
     a.reset()
     b.reset()
     assert torch.equal(a.obs, b.dense_obs())
@@ -171,6 +175,7 @@ def test_properties_at_4096_envs():
     whole = ScaledEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=9, env_offset=0)
     lo = ScaledEdgeSimGym(cfg, n_envs=B // 2, device="cuda:0", seed=9, env_offset=0)
     hi = ScaledEdgeSimGym(cfg, n_envs=B // 2, device="cuda:0", seed=9, env_offset=B // 2)
+    whole.set_envs_per_wave(4)          # the union on four environments per wavefront, the halves on one
     for e in (whole, lo, hi):
         e.reset()
     gen = torch.Generator(device="cuda:0").manual_seed(1)
