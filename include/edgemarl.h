@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 3
+#define EM_ABI_VERSION 4
 
 typedef enum em_status {
     EM_OK = 0,
@@ -438,6 +438,68 @@ int em_cc_grad(const em_central_critic *net, const float *ent_obs, const int32_t
                const uint8_t *k_arr, const int32_t *first_arr, int64_t n_global, float value_loss_coeff,
                float value_norm_mean, float value_norm_var, float *dz, float *slab, float *grad_out, float *loss3_out,
                void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * EdgeMARLEnv: the PyMARL twin environment (pymarl/src/envs/edge_marl_env.py), batched.  Its dynamics are not
+ * EdgeSimGym's: every agent holds a task every step, the clock advances before the placements, a placement adds the
+ * task's workload to the target's load, the reward uses the violation rate.  SURVEY.md 8f rank 4.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* EdgeMARLEnv.__init__ (edge_marl_env.py:18-58), defaults of config/envs/edge_marl.yaml. */
+typedef struct emm_config {
+    int32_t n_nodes;            /* agents == edge servers, 1..EM_MAX_NODES */
+    int32_t episode_length;     /* episode_limit */
+    int32_t arrival_mode;       /* 0 = fixed task_arrival_rate, 1 = "cyclic", 2 = "random" (edge_marl_env.py:236-243) */
+    int32_t action_mode;        /* 0 = "discrete", 1 = "hybrid" (edge_marl_env.py:98-104) */
+    double node_cpu_capacity[EM_MAX_NODES];
+    double arrival_rate, arrival_rate_lo, arrival_rate_hi, arrival_cycle_seconds;
+    double workload_lo, workload_hi;
+    double data_lo, data_hi;
+    double deadline_lo, deadline_hi;
+    double bw_lo, bw_hi;
+    double net_latency_lo, net_latency_hi;
+    double alpha, beta, gamma;  /* reward_weights */
+    double min_time_step, max_time_step;
+} emm_config;
+
+/* One step of pre-drawn random numbers (parity mode).  Device pointers; entries the reference would not have drawn
+ * (local placements, rate_u outside "random" mode) may hold anything. */
+typedef struct emm_tape {
+    const double *rate_u;               /* [n_envs]           rng.uniform(*rate_range)      edge_marl_env.py:242 */
+    const double *dt_raw;               /* [n_envs]           rng.exponential(1/rate)       :233 */
+    const double *bw_u;                 /* [n_envs][n_nodes]  rng.uniform(*bw_range), Mbps  :111 */
+    const double *net_lat;              /* [n_envs][n_nodes]  rng.uniform(*latency_range)   :112 */
+    const double *task_workload;        /* [n_envs][n_nodes]  :246 */
+    const double *task_data;            /* [n_envs][n_nodes]  :247 */
+    const double *task_deadline_offset; /* [n_envs][n_nodes]  :248 */
+} emm_tape;
+
+/* Outputs of reset/step; any pointer may be NULL to skip that output (reset fills obs only). */
+typedef struct emm_step_out {
+    float *obs;           /* [n_envs][n_nodes][n_nodes+4] f32 = get_obs (edge_marl_env.py:164-165,265-288); the same
+                             buffer read as [n_envs][n_nodes*(n_nodes+4)] is get_state (:173-174) */
+    double *reward;       /* [n_envs] (:145,290-294) */
+    uint8_t *terminated;  /* [n_envs] (:146) == info["episode_limit"] (:160) */
+    double *info;         /* [n_envs][6]: avg_latency_ms, avg_energy_J, deadline_violation_rate, throughput_tps,
+                             load_balance_jain (:154-160), then the mean latency in seconds as episode_metrics keeps it
+                             (:148; get_episode_summary, :193-207, is computed from a log of these rows) */
+    double *latency;      /* [n_envs][n_nodes] total_latency of each agent's task (:119) */
+} emm_step_out;
+
+typedef struct emm_handle emm_handle;
+
+/* seed/env_offset address the Philox stream of the throughput mode (environment b = global env_offset + b). */
+int emm_create(const emm_config *cfg, int64_t n_envs, int device_id, uint64_t seed, uint64_t env_offset, emm_handle **out);
+int emm_destroy(emm_handle *h);
+/* EdgeMARLEnv.reset (edge_marl_env.py:67-77); tape: only the three task arrays are read.  has_seed re-keys the
+ * Philox stream (EdgeMARLEnv.seed, :60-62). */
+int emm_reset(emm_handle *h, const emm_tape *tape, int has_seed, uint64_t seed, const emm_step_out *out, void *stream);
+/* EdgeMARLEnv.step (edge_marl_env.py:79-162).  Discrete mode: actions_i32 [n_envs][n_nodes], clipped to [0, n-1];
+ * hybrid mode: actions_f32 [n_envs][n_nodes][n_nodes+1] (_convert_hybrid_action, :304-318). */
+int emm_step(emm_handle *h, const int32_t *actions_i32, const float *actions_f32, const emm_tape *tape,
+             const emm_step_out *out, void *stream);
+/* Raw state for tests: load [n_envs][n] f64, queue [n_envs][n] f64, sim_time [n_envs] f64, step [n_envs] i32. */
+int emm_get_state(emm_handle *h, double *load, double *queue, double *sim_time, int32_t *step, void *stream);
 
 int em_abi_version(void);
 const char *em_last_error(void);

@@ -10,11 +10,11 @@ import os
 # device context, streams and allocations; loading /opt/rocm's copy first gives two runtimes.
 import torch  # noqa: F401
 
-from .config import EmConfig
+from .config import EmConfig, EmmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class EmTape(C.Structure):
@@ -76,6 +76,16 @@ class EmsRollout(C.Structure):
 class EmCentralCritic(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
                 ("b3", C.c_void_p), ("n_deciders", C.c_int32), ("width", C.c_int32), ("ldw", C.c_int32), ("pad", C.c_int32)]
+
+
+class EmmTape(C.Structure):
+    """ctypes image of ``emm_tape`` (EdgeMARLEnv parity mode)."""
+    _fields_ = [(name, C.c_void_p) for name in ("rate_u", "dt_raw", "bw_u", "net_lat", "task_workload", "task_data",
+                                                "task_deadline_offset")]
+
+
+class EmmStepOut(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in ("obs", "reward", "terminated", "info", "latency")]
 
 
 _lib = None
@@ -166,6 +176,13 @@ def lib() -> C.CDLL:
         getattr(L, name).restype = C.c_int
     for name in ("em_mlp3_forward", "em_rollout_index", "em_policy_step", "em_gae", "em_ppo_actor_grad",
                  "em_ppo_critic_grad", "em_adam_step"):
+        getattr(L, name).restype = C.c_int
+    L.emm_create.argtypes = [C.POINTER(EmmConfig), i64, i32, u64, u64, C.POINTER(vp)]
+    L.emm_destroy.argtypes = [vp]
+    L.emm_reset.argtypes = [vp, C.POINTER(EmmTape), i32, u64, C.POINTER(EmmStepOut), vp]
+    L.emm_step.argtypes = [vp, vp, vp, C.POINTER(EmmTape), C.POINTER(EmmStepOut), vp]
+    L.emm_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    for name in ("emm_create", "emm_destroy", "emm_reset", "emm_step", "emm_get_state"):
         getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",
                  "em_get_state", "em_set_lanes_per_env", "em_set_workgroup_waves", "em_step_raw", "em_step_greedy", "em_step_many"):

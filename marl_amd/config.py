@@ -97,3 +97,78 @@ def make_em_config(config: dict) -> EmConfig:
     c.final_epsilon = float(sch.get("final_epsilon", 0.05))
     c.decay_steps = int(sch.get("decay_steps", 1_000_000))
     return c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# EdgeMARLEnv (PyMARL twin environment): env_args of pymarl/src/config/envs/edge_marl.yaml:3-19
+# ---------------------------------------------------------------------------------------------------------------
+MARL_ENV_ARGS = {
+    "n_nodes": 10,
+    "node_cpu_capacity": [1.0e9, 1.2e9, 1.4e9, 1.6e9, 1.8e9, 2.0e9, 2.2e9, 2.4e9, 2.6e9, 3.0e9],
+    "task_arrival_rate": 10.0,
+    "task_arrival_rate_range": [5.0, 15.0],
+    "task_arrival_mode": "cyclic",
+    "task_arrival_cycle_seconds": 20.0,
+    "task_workload_range": [1.0, 10.0],
+    "task_data_range": [0.5, 5.0],
+    "task_deadline_range": [0.05, 0.5],
+    "network_bw_range": [10.0, 100.0],
+    "network_latency_range": [0.002, 0.01],
+    "reward_weights": {"alpha": 0.5, "beta": 0.3, "gamma": 0.2},
+    "min_time_step": 0.02,
+    "max_time_step": 0.2,
+    "initial_observation_window": 0.1,
+    "action_mode": "discrete",
+    "episode_length": 1000,
+}
+
+
+class EmmConfig(C.Structure):
+    """ctypes image of ``emm_config`` (include/edgemarl.h)."""
+
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("episode_length", C.c_int32), ("arrival_mode", C.c_int32), ("action_mode", C.c_int32),
+        ("node_cpu_capacity", C.c_double * EM_MAX_NODES),
+        ("arrival_rate", C.c_double), ("arrival_rate_lo", C.c_double), ("arrival_rate_hi", C.c_double),
+        ("arrival_cycle_seconds", C.c_double),
+        ("workload_lo", C.c_double), ("workload_hi", C.c_double),
+        ("data_lo", C.c_double), ("data_hi", C.c_double),
+        ("deadline_lo", C.c_double), ("deadline_hi", C.c_double),
+        ("bw_lo", C.c_double), ("bw_hi", C.c_double),
+        ("net_latency_lo", C.c_double), ("net_latency_hi", C.c_double),
+        ("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double),
+        ("min_time_step", C.c_double), ("max_time_step", C.c_double),
+    ]
+
+
+def make_emm_config(env_args: dict) -> EmmConfig:
+    """Same keys and defaults as EdgeMARLEnv.__init__ (edge_marl_env.py:18-41)."""
+    c = EmmConfig()
+    n = int(env_args.get("n_nodes", 10))
+    if not 1 <= n <= EM_MAX_NODES:
+        raise ValueError(f"n_nodes must be in 1..{EM_MAX_NODES}")
+    c.n_nodes = n
+    c.episode_length = int(env_args.get("episode_length", 1000))
+    mode = env_args.get("action_mode", "discrete")
+    if mode not in {"discrete", "hybrid"}:
+        raise ValueError("EdgeMARLEnv action_mode must be 'discrete' or 'hybrid'.")      # edge_marl_env.py:40-41
+    c.action_mode = 0 if mode == "discrete" else 1
+    c.arrival_mode = _ARRIVAL_MODES.get(env_args.get("task_arrival_mode", "cyclic"), 0)
+    c.arrival_rate = float(env_args.get("task_arrival_rate", 10.0))
+    c.arrival_rate_lo, c.arrival_rate_hi = map(float, env_args.get("task_arrival_rate_range", (5.0, 15.0)))
+    c.arrival_cycle_seconds = float(env_args.get("task_arrival_cycle_seconds", 20.0))
+    caps = np.asarray(env_args.get("node_cpu_capacity", np.ones(n) * 1e9), dtype=np.float64).reshape(-1)
+    if caps.size < n:
+        raise ValueError("node_cpu_capacity shorter than n_nodes")
+    for i in range(n):
+        c.node_cpu_capacity[i] = float(caps[i])
+    c.workload_lo, c.workload_hi = map(float, env_args.get("task_workload_range", (1.0, 10.0)))
+    c.data_lo, c.data_hi = map(float, env_args.get("task_data_range", (0.5, 5.0)))
+    c.deadline_lo, c.deadline_hi = map(float, env_args.get("task_deadline_range", (0.05, 0.5)))
+    c.bw_lo, c.bw_hi = map(float, env_args.get("network_bw_range", (10.0, 100.0)))
+    c.net_latency_lo, c.net_latency_hi = map(float, env_args.get("network_latency_range", (0.002, 0.01)))
+    w = env_args.get("reward_weights", {"alpha": 0.5, "beta": 0.3, "gamma": 0.2})
+    c.alpha, c.beta, c.gamma = float(w.get("alpha", 0.5)), float(w.get("beta", 0.3)), float(w.get("gamma", 0.2))
+    c.min_time_step = float(env_args.get("min_time_step", 0.02))
+    c.max_time_step = float(env_args.get("max_time_step", 0.2))
+    return c
