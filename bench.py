@@ -385,6 +385,62 @@ def scaled_leg(device, rank, world, B=65536, steps=300):
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
 
 
+def marl_env_leg(device, rank, world, B=65536, steps=400):
+    """EdgeMARLEnv (the PyMARL twin environment): emm_step, one lane per environment, discrete random
+    actions resident in HBM, in-kernel Philox stream.  Reported beside the headline."""
+    import torch.distributed as dist
+    from marl_amd.marl_env import EdgeMARLEnv
+    env = EdgeMARLEnv(n_envs=B, device=device, env_offset=rank * B, seed=0)
+    n, T = env.n_agents, env.episode_limit
+    gen = torch.Generator(device=device).manual_seed(7 + rank)
+    pool = [torch.randint(0, n, (B, n), device=device, generator=gen, dtype=torch.int32) for _ in range(8)]
+    stream = torch.cuda.current_stream(device)
+    counter = [0]
+    ptrs = [p.data_ptr() for p in pool]
+    env._out.info = env._log[0].data_ptr()
+    L, h, out, sptr = env._L, env._h, C.byref(env._out), stream.cuda_stream
+
+    def run(k):
+        for _ in range(k):
+            if counter[0] % T == 0:
+                env.reset()
+                env._out.info = env._log[0].data_ptr()
+            if L.emm_step(h, ptrs[counter[0] % 8], None, None, out, sptr):
+                raise RuntimeError(L.em_last_error().decode())
+            counter[0] += 1
+
+    run(40)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(steps)
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.close()
+    # algorithmic bytes per env-step (DESIGN.md 4.7): state arrays read and written (load, workload, data, deadline f64 +
+    # queue f32 per agent; clock f64 + step i32), actions read, observation tensor + reward + flag + 6 info scalars written
+    per_step = 2 * (n * 36 + 12) + 4 * n + 4 * n * (n + 4) + 8 + 1 + 48
+    ach = per_step * B / (dev_ms * 1e-3 / steps) / 1e9
+    return {"workload": "EdgeMARLEnv (PyMARL twin env), edge_marl.yaml defaults, discrete random actions, step-only",
+            "entry_point": "emm_step", "n_envs_per_gpu": B, "steps": steps, "env_steps_per_s": world * B * steps / elapsed,
+            "value": world * B * n * steps / elapsed, "unit": "agent-steps/s", "avg_launch_us": dev_ms * 1e3 / steps,
+            "roofline": {"bound": "hbm", "kernel": "marl_env_kernel<step>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
+
+
 def traffic_for(B):
     """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -428,9 +484,11 @@ def main():
         scale = (65536, k, e2, d2)
     fused = None
     scaled = None
+    marl_env = None
     if not args.no_scale_point:
         fused = fused_leg(device, rank, world, B)
         scaled = scaled_leg(device, rank, world)
+        marl_env = marl_env_leg(device, rank, world)
     mappo = None
     ippo = None
     mappo_scaled = None
@@ -481,6 +539,8 @@ def main():
             line["fused_steps"] = fused
         if scaled is not None:
             line["scaled_topology"] = scaled
+        if marl_env is not None:
+            line["pymarl_env"] = marl_env
         if mappo is not None:
             line["mappo"] = mappo
         if ippo is not None:

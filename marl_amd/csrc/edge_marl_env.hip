@@ -82,18 +82,18 @@ struct NpAcc {
 
 __device__ inline double uni(double u, double lo, double hi) { return lo + (hi - lo) * u; }
 
-// LDS: [n][T] float64 loads (reused as {ratio f32, deadline-remaining f32}) | [n][T] f32 queue | [n][T] f32 data | [n][T] f32 workload
+// LDS, rows T+1 apart: [n][T] float64 loads (reused as {ratio f32, deadline-remaining f32}) | [n][T] f32 queue | [n][T] f32 data | [n][T] f32 workload
 template <bool RESET>
 __global__ void marl_env_kernel(const MarlArgs a)
 {
     extern __shared__ double lds_raw[];
-    const int T = blockDim.x, tid = threadIdx.x;
+    const int T = blockDim.x, TS = T + 1, tid = threadIdx.x;
     const MarlConst* kc = a.kc;
     const int n = kc->n;
     double* l_load = lds_raw;
-    float* l_queue = reinterpret_cast<float*>(l_load + (size_t)n * T);
-    float* l_data = l_queue + (size_t)n * T;
-    float* l_wl = l_data + (size_t)n * T;
+    float* l_queue = reinterpret_cast<float*>(l_load + (size_t)n * TS);
+    float* l_data = l_queue + (size_t)n * TS;
+    float* l_wl = l_data + (size_t)n * TS;
     const int64_t B = a.n_envs, b0 = (int64_t)blockIdx.x * T, b = b0 + tid;
     const bool live = b < B;
     const uint32_t env_id_lo = (uint32_t)(a.env_offset + (uint64_t)b);
@@ -105,8 +105,8 @@ __global__ void marl_env_kernel(const MarlArgs a)
             sim_time = a.st.sim_time[b];
             step = a.st.step[b] + 1;
             for (int j = 0; j < n; ++j) {
-                l_load[j * T + tid] = a.st.load[(int64_t)j * B + b];
-                l_queue[j * T + tid] = a.st.queue[(int64_t)j * B + b];
+                l_load[j * TS + tid] = a.st.load[(int64_t)j * B + b];
+                l_queue[j * TS + tid] = a.st.queue[(int64_t)j * B + b];
             }
             // _sample_time_window (:230-234) with _current_task_rate (:236-243)
             double raw;
@@ -131,7 +131,18 @@ __global__ void marl_env_kernel(const MarlArgs a)
 
             NpAcc s_lat, s_en;
             int n_viol = 0;
+            // the next agent's task is fetched while the current one is evaluated (one lane cannot hide HBM latency otherwise)
+            const double* __restrict__ g_wl = a.st.wl;
+            const double* __restrict__ g_data = a.st.data;
+            const double* __restrict__ g_ddl = a.st.deadline;
+            double wl_nx = g_wl[b], data_nx = g_data[b], ddl_nx = g_ddl[b];
             for (int i = 0; i < n; ++i) {
+                const double wl = wl_nx, data = data_nx, deadline = ddl_nx;
+                if (i + 1 < n) {
+                    wl_nx = g_wl[(int64_t)(i + 1) * B + b];
+                    data_nx = g_data[(int64_t)(i + 1) * B + b];
+                    ddl_nx = g_ddl[(int64_t)(i + 1) * B + b];
+                }
                 int target;
                 double share;
                 if (kc->action_mode == 0) {
@@ -154,9 +165,7 @@ __global__ void marl_env_kernel(const MarlArgs a)
                     nrm = nrm < 0.0 ? 0.0 : (nrm > 1.0 ? 1.0 : nrm);
                     share = 0.1 + 0.9 * nrm;
                 }
-                const double wl = a.st.wl[(int64_t)i * B + b], data = a.st.data[(int64_t)i * B + b];
-                const double deadline = a.st.deadline[(int64_t)i * B + b];
-                const double placement_load = l_load[target * T + tid];
+                const double placement_load = l_load[target * TS + tid];
                 double transfer = 0.0;
                 if (target != i) {
                     double bw_u, net_lat;
@@ -181,20 +190,20 @@ __global__ void marl_env_kernel(const MarlArgs a)
                 s_lat.add(i, n, total);
                 s_en.add(i, n, energy);
                 n_viol += (sim_time + total) > deadline ? 1 : 0;                            // :125
-                l_load[target * T + tid] = placement_load + wl;                             // :127
-                l_queue[target * T + tid] += 1.0f;
+                l_load[target * TS + tid] = placement_load + wl;                             // :127
+                l_queue[target * TS + tid] += 1.0f;
                 if (a.out.latency) a.out.latency[b * n + i] = total;
             }
             // _advance_system (:256-259) and the Jain index of load + 1e-6 (:143,296-302)
             NpAcc s_v, s_v2;
             for (int j = 0; j < n; ++j) {
                 const double processed = kc->cap[j] * window;
-                double l = l_load[j * T + tid] - processed;
+                double l = l_load[j * TS + tid] - processed;
                 l = l > 0.0 ? l : 0.0;
-                float q = l_queue[j * T + tid] - 1.0f;
+                float q = l_queue[j * TS + tid] - 1.0f;
                 q = q > 0.0f ? q : 0.0f;
-                l_load[j * T + tid] = l;
-                l_queue[j * T + tid] = q;
+                l_load[j * TS + tid] = l;
+                l_queue[j * TS + tid] = q;
                 a.st.load[(int64_t)j * B + b] = l;
                 a.st.queue[(int64_t)j * B + b] = q;
                 const double v = l + 1e-6;
@@ -216,8 +225,8 @@ __global__ void marl_env_kernel(const MarlArgs a)
             }
         } else {
             for (int j = 0; j < n; ++j) {                                                   // reset, :67-73
-                l_load[j * T + tid] = 0.0;
-                l_queue[j * T + tid] = 0.0f;
+                l_load[j * TS + tid] = 0.0;
+                l_queue[j * TS + tid] = 0.0f;
                 a.st.load[(int64_t)j * B + b] = 0.0;
                 a.st.queue[(int64_t)j * B + b] = 0.0f;
             }
@@ -244,34 +253,40 @@ __global__ void marl_env_kernel(const MarlArgs a)
             a.st.data[(int64_t)i * B + b] = data;
             a.st.deadline[(int64_t)i * B + b] = deadline;
             const double rem = deadline - sim_time;
-            const double ratio = l_load[i * T + tid] / (kc->cap[i] + 1e-9);                 // :266
+            const double ratio = l_load[i * TS + tid] / (kc->cap[i] + 1e-9);                 // :266
             float2 pr;
             pr.x = (float)ratio;
             pr.y = (float)(rem > 0.0 ? rem : 0.0);
-            *reinterpret_cast<float2*>(&l_load[i * T + tid]) = pr;
-            l_data[i * T + tid] = (float)data;
-            l_wl[i * T + tid] = (float)wl;
+            *reinterpret_cast<float2*>(&l_load[i * TS + tid]) = pr;
+            l_data[i * TS + tid] = (float)data;
+            l_wl[i * TS + tid] = (float)wl;
         }
     }
     if (!a.out.obs) return;
     __syncthreads();
-    // the workgroup's observation rows are one contiguous range of the output: [env][agent][n+4]
+    // the workgroup's observation rows are one contiguous range of the output, [env][agent][n+4]: a thread owns a fixed
+    // (agent, column) and walks the environments, so consecutive lanes store consecutive floats and the index arithmetic
+    // is done once (rows are TS = T+1 apart in LDS: lanes that read different agents of one environment hit different banks)
     const int w = n + 4, per_env = n * w;
-    const int64_t envs_here = B - b0 < T ? B - b0 : T;
-    const int64_t total = envs_here * per_env;
+    const int envs_here = (int)(B - b0 < T ? B - b0 : T);
     float* dst = a.out.obs + b0 * per_env;
     const float2* l_pair = reinterpret_cast<const float2*>(l_load);
-    for (int64_t e = tid; e < total; e += T) {
-        const int el = (int)(e / per_env), rem = (int)(e - (int64_t)el * per_env);
-        const int i = rem / w, c = rem - i * w;
-        float v;
-        if (c == 0) v = l_pair[i * T + el].x;
-        else if (c == 1) v = l_queue[i * T + el];
-        else if (c == 2) v = l_data[i * T + el];
-        else if (c == 3) v = l_wl[i * T + el];
-        else if (c == 4) v = l_pair[i * T + el].y;
-        else { const int j = c - 5; v = l_pair[(j < i ? j : j + 1) * T + el].x; }           // neighbours in index order, :278-282
-        dst[e] = v;
+    constexpr int SPLIT = 8;                            // environment ranges per (agent, column): work for every lane
+    const int chunk = (envs_here + SPLIT - 1) / SPLIT;
+    for (int item = tid; item < per_env * SPLIT; item += T) {
+        const int part = item / per_env, base = item - part * per_env;
+        const int i = base / w, c = base - i * w;
+        const int el0 = part * chunk, el1 = el0 + chunk < envs_here ? el0 + chunk : envs_here;
+        const float* src;
+        int stride_f;                                   // LDS stride between environments, in floats
+        if (c == 0) { src = &l_pair[i * TS].x; stride_f = 2; }
+        else if (c == 1) { src = &l_queue[i * TS]; stride_f = 1; }
+        else if (c == 2) { src = &l_data[i * TS]; stride_f = 1; }
+        else if (c == 3) { src = &l_wl[i * TS]; stride_f = 1; }
+        else if (c == 4) { src = &l_pair[i * TS].y; stride_f = 2; }
+        else { const int j = c - 5; src = &l_pair[(j < i ? j : j + 1) * TS].x; stride_f = 2; }   // neighbours in index order, :278-282
+        float* d = dst + base;
+        for (int el = el0; el < el1; ++el) d[(int64_t)el * per_env] = src[el * stride_f];
     }
 }
 
@@ -349,15 +364,16 @@ int emm_create(const emm_config* cfg, int64_t n_envs, int device_id, uint64_t se
     // 20 bytes of LDS per (agent, lane): as many lanes per workgroup as fit 64 KB, at most 256
     const size_t per_lane = (size_t)n * 20;
     int threads = 256;
-    while (threads > 64 && per_lane * threads > 64 * 1024) threads >>= 1;
+    while (threads > 64 && per_lane * (threads + 1) > 64 * 1024) threads >>= 1;
     h->threads = threads;
-    h->lds_bytes = per_lane * threads;
+    h->lds_bytes = per_lane * (threads + 1);
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&marl_env_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&marl_env_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) {
+            const size_t need = h->lds_bytes;
             delete h;
-            return em::fail(EM_ERR_INVALID, "emm_create: n_nodes %d needs %zu bytes of LDS per workgroup, which this device refuses", n, (size_t)per_lane * threads);
+            return em::fail(EM_ERR_INVALID, "emm_create: n_nodes %d needs %zu bytes of LDS per workgroup, which this device refuses", n, need);
         }
     }
     MarlConst kc;

@@ -85,7 +85,7 @@ class EdgeMARLEnv:
         B, n, d = self.n_envs, self.n_agents, self.device
         self.obs = torch.zeros((B, n, n + 4), dtype=torch.float32, device=d)
         self.reward = torch.zeros(B, dtype=torch.float64, device=d)
-        self.terminated = torch.zeros(B, dtype=torch.uint8, device=d)
+        self.terminated = torch.zeros(B, dtype=torch.bool, device=d)        # the kernel stores 0/1 bytes
         self.latency = None
         self._log = torch.zeros((self.episode_limit, B, 6), dtype=torch.float64, device=d)
         self._avail = torch.ones((B, n, n), dtype=torch.int32, device=d)
@@ -150,9 +150,8 @@ class EdgeMARLEnv:
                                         _stream_ptr(self.device)), "emm_step")
         self.current_step += 1
         info = {k: row[:, j] for j, k in enumerate(INFO_KEYS)}
-        term = self.terminated.bool()
-        info["episode_limit"] = term                                                       # edge_marl_env.py:160
-        return self.reward, term, info
+        info["episode_limit"] = self.terminated                                            # edge_marl_env.py:160
+        return self.reward, self.terminated, info
 
     def get_obs(self):
         return self.obs
