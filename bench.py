@@ -385,12 +385,13 @@ def scaled_leg(device, rank, world, B=65536, steps=300):
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
 
 
-def marl_env_leg(device, rank, world, B=65536, steps=400):
+def marl_env_leg(device, rank, world, B=65536, steps=400, lanes=0):
     """EdgeMARLEnv (the PyMARL twin environment): emm_step, one lane per environment, discrete random
     actions resident in HBM, in-kernel Philox stream.  Reported beside the headline."""
     import torch.distributed as dist
     from marl_amd.marl_env import EdgeMARLEnv
     env = EdgeMARLEnv(n_envs=B, device=device, env_offset=rank * B, seed=0)
+    env.set_lanes_per_env(lanes)
     n, T = env.n_agents, env.episode_limit
     gen = torch.Generator(device=device).manual_seed(7 + rank)
     pool = [torch.randint(0, n, (B, n), device=device, generator=gen, dtype=torch.int32) for _ in range(8)]

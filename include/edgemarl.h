@@ -498,6 +498,10 @@ int emm_reset(emm_handle *h, const emm_tape *tape, int has_seed, uint64_t seed, 
  * hybrid mode: actions_f32 [n_envs][n_nodes][n_nodes+1] (_convert_hybrid_action, :304-318). */
 int emm_step(emm_handle *h, const int32_t *actions_i32, const float *actions_f32, const emm_tape *tape,
              const emm_step_out *out, void *stream);
+/* Kernel variant: 1 lane per environment (large batches) or 16 lanes per environment (n_nodes <= 16; small batches);
+ * 0 = the library's choice (16 lanes up to 32,768 environments).  Identical results; tuning and tests only.  No
+ * counterpart in the reference. */
+int emm_set_lanes_per_env(emm_handle *h, int32_t lanes_per_env);
 /* Raw state for tests: load [n_envs][n] f64, queue [n_envs][n] f64, sim_time [n_envs] f64, step [n_envs] i32. */
 int emm_get_state(emm_handle *h, double *load, double *queue, double *sim_time, int32_t *step, void *stream);
 

@@ -182,6 +182,8 @@ def lib() -> C.CDLL:
     L.emm_reset.argtypes = [vp, C.POINTER(EmmTape), i32, u64, C.POINTER(EmmStepOut), vp]
     L.emm_step.argtypes = [vp, vp, vp, C.POINTER(EmmTape), C.POINTER(EmmStepOut), vp]
     L.emm_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.emm_set_lanes_per_env.argtypes = [vp, i32]
+    L.emm_set_lanes_per_env.restype = C.c_int
     for name in ("emm_create", "emm_destroy", "emm_reset", "emm_step", "emm_get_state"):
         getattr(L, name).restype = C.c_int
     for name in ("em_create", "em_destroy", "em_reset", "em_step", "em_episode_metrics", "em_set_exploration",

@@ -99,6 +99,10 @@ class EdgeMARLEnv:
         self.latency = torch.zeros((self.n_envs, self.n_agents), dtype=torch.float64, device=self.device)
         self._out.latency = self.latency.data_ptr()
 
+    def set_lanes_per_env(self, lanes_per_env: int):
+        """Kernel variant: 1, 16 or 0 (automatic); tuning/tests only, identical results."""
+        _lib.check(self._L.emm_set_lanes_per_env(self._h, int(lanes_per_env)), "emm_set_lanes_per_env")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.emm_destroy(self._h)

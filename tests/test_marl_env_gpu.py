@@ -22,13 +22,17 @@ def _tape_row(env_mod, tape, s, B, reset=False):
     return env_mod.MarlDeviceTape(arrays, DEV)
 
 
+@pytest.mark.parametrize("lanes", (1, 16))
 @pytest.mark.parametrize("name", fx.FIXTURES)
-def test_reference_episode_bit_exact(name):
+def test_reference_episode_bit_exact(name, lanes):
     from marl_amd import marl_env
     args, z, out, tape = fx.replay(name)
-    B, steps = 3, len(z["reward"])
+    if lanes == 16 and int(args["n_nodes"]) > 16:
+        pytest.skip("16 lanes per environment need n_nodes <= 16")
+    B, steps = 3 if lanes == 1 else 21, len(z["reward"])
     kw = {k: v for k, v in args.items() if k != "seed"}
     env = marl_env.EdgeMARLEnv(n_envs=B, device=DEV, **kw)
+    env.set_lanes_per_env(lanes)
     env.enable_debug_outputs()
     env.reset(tape=_tape_row(marl_env, tape, 0, B, reset=True))
     assert np.array_equal(env.get_obs().cpu().numpy(), np.repeat(z["obs"][0][None], B, 0))
@@ -48,9 +52,10 @@ def test_reference_episode_bit_exact(name):
     env.close()
 
 
-def _philox_case(kw, B, steps, seed, env_offset, rng):
+def _philox_case(kw, B, steps, seed, env_offset, rng, lanes=1):
     from marl_amd import marl_env
     env = marl_env.EdgeMARLEnv(n_envs=B, device=DEV, env_offset=env_offset, seed=seed, **kw)
+    env.set_lanes_per_env(lanes)
     env.enable_debug_outputs()
     n = env.n_agents
     args = dict(marl_env.MARL_ENV_ARGS); args.update(kw)
@@ -82,8 +87,10 @@ def _philox_case(kw, B, steps, seed, env_offset, rng):
     env.close()
 
 
-def test_philox_stream_cyclic_hybrid():
-    _philox_case({"action_mode": "hybrid", "episode_length": 20}, B=40, steps=22, seed=2024, env_offset=1000, rng=np.random.RandomState(0))
+@pytest.mark.parametrize("lanes", (1, 16))
+def test_philox_stream_cyclic_hybrid(lanes):
+    _philox_case({"action_mode": "hybrid", "episode_length": 20}, B=40, steps=22, seed=2024, env_offset=1000,
+                 rng=np.random.RandomState(0), lanes=lanes)
 
 
 def test_philox_stream_random_rate_wide_two_workgroups():
@@ -91,9 +98,40 @@ def test_philox_stream_random_rate_wide_two_workgroups():
     _philox_case(kw, B=150, steps=5, seed=7, env_offset=0, rng=np.random.RandomState(1))
 
 
-def test_philox_stream_fixed_rate_tiny():
+@pytest.mark.parametrize("lanes", (1, 16))
+def test_philox_stream_fixed_rate_tiny(lanes):
     kw = {"n_nodes": 3, "node_cpu_capacity": [1e9, 2e9, 3e9], "task_arrival_mode": "fixed", "task_arrival_rate": 30.0, "episode_length": 9}
-    _philox_case(kw, B=300, steps=9, seed=5, env_offset=2**32 - 100, rng=np.random.RandomState(2))
+    _philox_case(kw, B=300, steps=9, seed=5, env_offset=2**32 - 100, rng=np.random.RandomState(2), lanes=lanes)
+
+
+def test_philox_stream_sixteen_nodes_random_rate():
+    kw = {"n_nodes": 16, "node_cpu_capacity": list(np.linspace(1e9, 3e9, 16)), "task_arrival_mode": "random", "episode_length": 30}
+    _philox_case(kw, B=35, steps=6, seed=21, env_offset=3, rng=np.random.RandomState(4), lanes=16)
+
+
+def test_lane_variants_agree_at_full_size():
+    """4,096 environments, 60 steps: the two kernel variants produce identical outputs and state."""
+    from marl_amd import marl_env
+    B = 4096
+    envs = []
+    for lanes in (1, 16):
+        e = marl_env.EdgeMARLEnv(n_envs=B, device=DEV, seed=9, episode_length=60)
+        e.set_lanes_per_env(lanes)
+        e.seed(9); e.reset()
+        envs.append(e)
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    for t in range(60):
+        a = torch.randint(0, 10, (B, 10), device=DEV, dtype=torch.int32, generator=g)
+        outs = [e.step(a) for e in envs]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for k in marl_env.INFO_KEYS:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+        assert torch.equal(envs[0].get_obs(), envs[1].get_obs())
+    s0, s1 = envs[0].raw_state(), envs[1].raw_state()
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+    with pytest.raises(RuntimeError):
+        envs[0].set_lanes_per_env(4)
 
 
 def test_philox_stream_max_nodes():
