@@ -176,8 +176,7 @@ class IPPO:
         return dict(self.last_update)
 
     def _sum_moments(self) -> int:
-        if self.sync.enabled and self.sync.world_size > 1:
-            self.sync.dist.all_reduce(self.moments, op=self.sync.dist.ReduceOp.SUM, group=self.sync.group)
+        self.sync.sum_grads(self.moments)          # plain SUM over ranks of the [G, 3] float64 moments
         return int(round(float(self.moments[:, 0].sum().item())))
 
     # -- checkpoint: flat parameter and Adam buffers --------------------------------------------------------------------

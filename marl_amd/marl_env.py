@@ -208,3 +208,87 @@ class EdgeMARLEnv:
             _lib.check(self._L.emm_get_state(self._h, st["load"].data_ptr(), st["queue"].data_ptr(), st["sim_time"].data_ptr(),
                                              st["step"].data_ptr(), _stream_ptr(self.device)), "emm_get_state")
         return {k: v.cpu().numpy() for k, v in st.items()}
+
+
+class EdgeMARLEnvHost:
+    """One environment with the reference's host-side types: what ``REGISTRY["edge_marl"]`` (pymarl/src/envs/__init__.py:20)
+    binds for PyMARL's episode runner, which steps one environment per process and expects a float reward, a bool flag,
+    a dict of floats, a list of numpy observation rows and a numpy state.  Every call is one kernel launch plus one small
+    device-to-host copy; batched collectors should use ``EdgeMARLEnv`` and keep everything on the device."""
+
+    def __init__(self, device="cuda:0", **env_args):
+        self._env = EdgeMARLEnv(n_envs=1, device=device, **env_args)
+        for name in ("n_agents", "episode_limit", "action_mode", "hybrid_action_dim", "obs_dim", "state_dim"):
+            setattr(self, name, getattr(self._env, name))
+
+    def seed(self, seed: int):
+        self._env.seed(seed)
+
+    def reset(self):
+        self._env.reset()
+
+    def step(self, actions):
+        n = self.n_agents
+        if len(actions) != n:
+            raise ValueError("Actions must be provided for each agent.")                   # edge_marl_env.py:80-81
+        rows = [a.detach().cpu().numpy() if hasattr(a, "cpu") else np.asarray(a) for a in actions]
+        if self.action_mode == "discrete":
+            vals = np.array([np.clip(r, 0, n - 1).reshape(-1)[0] for r in rows])          # int(np.clip(...)), :101
+            a = torch.as_tensor(vals.astype(np.int32)[None], device=self._env.device)
+        else:
+            mat = np.zeros((n, n + 1), dtype=np.float32)
+            for i, r in enumerate(rows):                                                  # zero padding of short vectors, :305-309
+                v = np.asarray(r, dtype=np.float32).reshape(-1)
+                if v.size > n + 1:
+                    v = np.concatenate([v[:n], v[-1:]])                                   # logits = the first n, resource = the last
+                mat[i, :v.size] = v
+            a = torch.as_tensor(mat[None], device=self._env.device)
+        reward, term, info = self._env.step(a)
+        host = torch.stack([info[k][0] for k in INFO_KEYS] + [reward[0]]).cpu().numpy()
+        terminated = bool(term[0].item())
+        out = {k: float(host[j]) for j, k in enumerate(INFO_KEYS)}
+        out["episode_limit"] = terminated
+        return float(host[-1]), terminated, out
+
+    def get_obs(self):
+        o = self._env.get_obs()[0].cpu().numpy()
+        return [o[i] for i in range(self.n_agents)]
+
+    def get_obs_agent(self, agent_id):
+        return self._env.get_obs()[0, agent_id].cpu().numpy()
+
+    def get_obs_size(self):
+        return self.obs_dim
+
+    def get_state(self):
+        return self._env.get_state()[0].cpu().numpy()
+
+    def get_state_size(self):
+        return self.state_dim
+
+    def get_avail_actions(self):
+        return np.ones((self.n_agents, self.get_total_actions()), dtype=np.int32)
+
+    def get_avail_agent_actions(self, agent_id):
+        return np.ones(self.get_total_actions(), dtype=np.int32)
+
+    def get_total_actions(self):
+        return self.n_agents
+
+    def get_action_dim(self):
+        return self._env.get_action_dim()
+
+    def get_episode_summary(self):
+        return {k: float(v[0]) for k, v in self._env.get_episode_summary().items()}
+
+    def get_env_info(self):
+        return self._env.get_env_info()
+
+    def close(self):
+        self._env.close()
+
+    def render(self):
+        return
+
+    def save_replay(self):
+        return

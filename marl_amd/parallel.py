@@ -23,20 +23,31 @@ class GradSync:
         self.enabled = (dist.is_available() and dist.is_initialized()) if enabled is None else bool(enabled)
         self.world_size = dist.get_world_size(process_group) if self.enabled else 1
         self.rank = dist.get_rank(process_group) if self.enabled else 0
+        # gloo (the CPU test rig; production is "nccl" = RCCL) stages device tensors through the host from its own
+        # threads: with kernels still in flight on the caller's stream that was seen to deadlock two ranks sharing one
+        # GPU (both stuck inside all_reduce), so the stream is drained first.  RCCL orders itself on the stream.
+        self._drain = self.enabled and dist.get_backend(process_group) == "gloo"
+
+    def _ready(self, t: torch.Tensor) -> None:
+        if self._drain and t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
 
     def sum_moments(self, moments: torch.Tensor) -> int:
         """In-place SUM over ranks; returns the global transition count."""
         if self.enabled and self.world_size > 1:
+            self._ready(moments)
             self.dist.all_reduce(moments, op=self.dist.ReduceOp.SUM, group=self.group)
         return int(round(float(moments[0].item())))
 
     def sum_grads(self, flat: torch.Tensor) -> None:
         if self.enabled and self.world_size > 1:
+            self._ready(flat)
             self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, flat: torch.Tensor, src: int = 0) -> None:
         """Replicas start from rank src's parameters (seeded init is already identical; this is a safety net)."""
         if self.enabled and self.world_size > 1:
+            self._ready(flat)
             self.dist.broadcast(flat, src=src, group=self.group)
 
 

@@ -201,3 +201,37 @@ def test_full_size_properties():
     s = env.get_episode_summary()
     assert np.isfinite(s["p99_latency_ms"]).all() and (s["p99_latency_ms"] >= s["avg_latency_ms"] * 0.5).all()
     env.close()
+
+
+def test_host_view_matches_batched_row_and_reference_types():
+    """The n_envs = 1 adapter PyMARL's registry binds: host types, same numbers as row 0 of the batched environment."""
+    from marl_amd import marl_env
+    host = marl_env.EdgeMARLEnvHost(device=DEV, seed=4, episode_length=6)
+    ref = marl_env.EdgeMARLEnv(n_envs=3, device=DEV, seed=4, episode_length=6)
+    n = host.n_agents
+    obs = host.get_obs()
+    assert isinstance(obs, list) and len(obs) == n and obs[0].dtype == np.float32 and obs[0].shape == (n + 4,)
+    assert np.array_equal(np.stack(obs), ref.get_obs()[0].cpu().numpy())
+    assert np.array_equal(host.get_state(), np.concatenate(obs))
+    assert host.get_avail_actions().shape == (n, n) and host.get_avail_agent_actions(0).dtype == np.int32
+    rng = np.random.RandomState(0)
+    for t in range(6):
+        acts = rng.randint(-2, n + 2, size=n)
+        feed = [torch.tensor(acts[i]) if i % 2 else np.int64(acts[i]) for i in range(n)]     # tensors and numpy scalars, :99-101
+        r, term, info = host.step(feed)
+        rb, tb, ib = ref.step(torch.as_tensor(np.repeat(acts[None], 3, 0).astype(np.int32), device=DEV))
+        assert isinstance(r, float) and isinstance(term, bool) and isinstance(info["avg_latency_ms"], float)
+        assert r == float(rb[0]) and term == bool(tb[0]) and info["episode_limit"] == term
+        assert info["load_balance_jain"] == float(ib["load_balance_jain"][0])
+    assert term
+    s = host.get_episode_summary()
+    assert s["p99_latency_ms"] == float(ref.get_episode_summary()["p99_latency_ms"][0])
+    with pytest.raises(ValueError):
+        host.step([0] * (n - 1))
+    hy = marl_env.EdgeMARLEnvHost(device=DEV, seed=4, action_mode="hybrid")
+    assert hy.get_action_dim() == n + 1
+    r, _, _ = hy.step([np.array([0.1, 0.9])] * n)            # short vectors are zero padded: placement 1, resource norm 0.5
+    hy2 = marl_env.EdgeMARLEnv(n_envs=1, device=DEV, seed=4, action_mode="hybrid")
+    full = np.zeros((1, n, n + 1), np.float32); full[0, :, 0] = 0.1; full[0, :, 1] = 0.9
+    assert r == float(hy2.step(torch.as_tensor(full, device=DEV))[0][0])
+    host.close(); ref.close(); hy.close(); hy2.close()
