@@ -150,7 +150,7 @@ def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
     import torch.distributed as dist
     from marl_amd.ippo import IPPOTrainer
     tr = IPPOTrainer(None, seed=0, device=device, n_envs=n_envs, rank=rank, world_size=world, verbose=False, algorithm=algorithm)
-    T = tr.env.episode_len
+    T, D = tr.env.episode_len, tr.D
 
     def iteration():
         t0 = time.perf_counter()
@@ -197,7 +197,7 @@ def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
                 "collective": "1 all-reduce of 1,131,336 floats per epoch + 3 doubles per update" if world > 1 else "none"}
     return {"metric": "IPPO samples/sec (scaled topology: transitions through rollout + per-agent GAE + 4-epoch PPO update)",
             "value": entries / elapsed, "unit": "transitions/s", "env_steps_per_s": world * n_envs * T * iters / elapsed,
-            "agent_steps_per_s": world * n_envs * T * tr.D * iters / elapsed, "n_envs_per_gpu": n_envs, "learners": tr.D,
+            "agent_steps_per_s": world * n_envs * T * D * iters / elapsed, "n_envs_per_gpu": n_envs, "learners": D,
             "iterations": iters, "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters,
             "update_s_rank0": upd / iters, "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
             "parity": "unpinned vs the reference (RLlib IPPO not vendored); pinned to oracle/ippo_oracle.py",
