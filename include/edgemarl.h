@@ -175,6 +175,10 @@ int em_set_workgroup_waves(em_handle *h, int waves);
  * the library returns the pending list in arrival order instead of a dense [D][S+4] tensor that is >99 % zeros.
  * ---------------------------------------------------------------------------------------------- */
 #define EMS_PENDING_CAP 64
+#define EMS_INDEX_CURSOR_STRIDE 32
+/* chunk totals + histogram + flag, rounded up to a 128-byte line, then one line per group cursor */
+#define EMS_INDEX_SCRATCH_INTS(n_envs, n_deciders) \
+    (((((n_envs) + 255) / 256 + (n_deciders) + 1 + 31) / 32) * 32 + 32 * (int64_t)(n_deciders))
 #define EMS_MAX_DECIDERS 4096
 
 typedef struct ems_handle ems_handle;
@@ -238,7 +242,8 @@ typedef struct ems_rollout {
     int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller     */
     int32_t *ent_state;    /* [E] state row of the entry = step * n_envs + env (central critic); may be NULL */
     float *value_tb;       /* [T][B] central-critic value of the (step, env) state; may be NULL        */
-    int32_t *index_scratch; /* [ceil(B/256) + 2*n_deciders + 1] scratch of ems_rollout_index, zeroed by the caller once */
+    int32_t *index_scratch; /* [EMS_INDEX_SCRATCH_INTS(B, n_deciders)] scratch of ems_rollout_index, 128-byte aligned,
+                               zeroed by the caller once */
 } ems_rollout;
 
 /* Records which deciders act at step t (the pending lists ems_reset/ems_step returned): numbers the entries, copies
