@@ -304,7 +304,19 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
     float* scr = lds + L::END + wave * (HID * TS);     // per-wavefront transpose scratch [64][TS]
     stage_weights<KU, OT>(lds, a.net, ACTOR ? a.log_std : nullptr, g);
+    // per-output constants of the Gaussian log-density, evaluated once per workgroup instead of three exp() and a
+    // reciprocal per element and tile: 2*sd^2 and 1/sd^2 (same expressions, so the same bits as evaluating them in place)
+    float* den_t = lds + L::END + 4 * (HID * TS);
+    float* iv_t = den_t + 16 * OT;
     __syncthreads();
+    if constexpr (ACTOR) {
+        if (threadIdx.x < 16 * OT) {
+            const float sd = expf(lds[L::LS + threadIdx.x]);
+            den_t[threadIdx.x] = 2.0f * (sd * sd);
+            iv_t[threadIdx.x] = 1.0f / (sd * sd);
+        }
+        __syncthreads();
+    }
 
     f32x4 gW1[4][KU], gW2[4][4], gW3[OT][4], gb1[4], gb2[4], gb3[OT], gls[OT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -362,9 +374,9 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     const int o = 16 * ot + 4 * q + r;
                     float d = 0.0f;
                     if (o < O && valid) {
-                        const float ls = lds[L::LS + o], sd = expf(ls);
+                        const float ls = lds[L::LS + o];
                         d = a.action[grow * O + o] - y[ot][r];
-                        lp += -(d * d) / (2.0f * (sd * sd)) - ls - HALF_LOG_2PI;
+                        lp += -(d * d) / den_t[o] - ls - HALF_LOG_2PI;
                     }
                     dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
                 }
@@ -391,8 +403,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     const float d = dy[ot][r];
                     float out = 0.0f;
                     if (o < O && valid) {
-                        const float sd = expf(lds[L::LS + o]);
-                        const float iv = 1.0f / (sd * sd);
+                        const float iv = iv_t[o];
                         out = g_lp * d * iv;                                // d logp / d mu
                         gls[ot][r] += g_lp * (d * d * iv - 1.0f) - a.ecoef * inv_L;   // d logp / d log_std ; entropy bonus
                     }
@@ -692,7 +703,7 @@ int check_gnet(const em_gmlp* net)
 size_t lds_bytes(int ku, int ot, bool bwd)
 {
     const int s1 = (ku * 16 + 2) | 2;
-    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS : 0));
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 0));
 }
 
 template <typename K>

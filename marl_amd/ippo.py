@@ -100,6 +100,7 @@ class IPPO:
         self._chain = torch.zeros((int(n_envs), self.D, 2), dtype=torch.float64, device=self.device)
         # workgroups per network: independent learners map one network per CU; a shared network uses the whole chip
         self.split = 1 if self.G >= 64 else max(1, 256 // self.G)
+        self.fwd_split = self.split          # workgroups per network in the rollout forwards (rows are independent)
         self._slab_a = self._slab_c = None
         self.last_update = {}
 
@@ -113,9 +114,9 @@ class IPPO:
                                                  env.pend_decider.data_ptr(), env.pend_obs.data_ptr(), _stream(self.device)),
                        "ems_rollout_index")
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
-                    tt["ent_action"], tt["ent_logp"], tt["group_off"], tt["perm"], self.split, noise=noise, explore=explore,
+                    tt["ent_action"], tt["ent_logp"], tt["group_off"], tt["perm"], self.fwd_split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
-        gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.split)
+        gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.fwd_split)
         ro.steps_recorded = t + 1
 
     # -- update ----------------------------------------------------------------------------------------------------------

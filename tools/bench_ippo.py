@@ -16,11 +16,18 @@ def main():
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--shared", action="store_true")
+    ap.add_argument("--fwd-split", type=int, default=0)
+    ap.add_argument("--bwd-split", type=int, default=0)
     ap.add_argument("--algorithm", default="ippo", choices=["ippo", "shared", "mappo"])
     a = ap.parse_args()
     cfg = dict(SCALED_ENV_CONFIG)
     cfg["episode_length"] = a.horizon
     tr = IPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=a.envs, algorithm="shared" if a.shared else a.algorithm, verbose=False)
+    if a.fwd_split:
+        tr.algo.fwd_split = a.fwd_split
+    if a.bwd_split:
+        tr.algo.split = a.bwd_split
+        tr.algo._slab_a = tr.algo._slab_c = None
     for it in range(a.iters + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
