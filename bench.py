@@ -442,6 +442,17 @@ def marl_env_leg(device, rank, world, B=65536, steps=400, lanes=0):
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
 
 
+def guarded(name, fn, *a, **k):
+    """Secondary legs (everything beside the headline measurement) must not cost the headline line: a Python-level
+    failure is reported in the leg's object and on stderr.  The same code runs on every rank, so a deterministic failure
+    is caught on all of them and no rank is left waiting in a collective."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] {name} leg failed: {e!r}", file=sys.stderr, flush=True)
+        return {"error": repr(e)[:300]}
+
+
 def traffic_for(B):
     """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -469,8 +480,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal of the N > 1 code path on a one-GPU box: EDGEMARL_BENCH_BACKEND=gloo EDGEMARL_BENCH_DEVICE=0 puts every
+        # rank on one card over gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+        backend = os.environ.get("EDGEMARL_BENCH_BACKEND", "nccl")
+        local_rank = int(os.environ.get("EDGEMARL_BENCH_DEVICE", local_rank))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -481,22 +499,22 @@ def main():
     if not args.no_scale_point and B != 65536:
         # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)
         k = max(200, args.steps // 4)
-        e2, d2, _, _, _ = time_env_steps(device, rank, world, 65536, k, max(20, args.warmup // 4))
-        scale = (65536, k, e2, d2)
+        res = guarded("scale_point", time_env_steps, device, rank, world, 65536, k, max(20, args.warmup // 4))
+        scale = (65536, k, res[0], res[1]) if isinstance(res, tuple) else None
     fused = None
     scaled = None
     marl_env = None
     if not args.no_scale_point:
-        fused = fused_leg(device, rank, world, B)
-        scaled = scaled_leg(device, rank, world)
-        marl_env = marl_env_leg(device, rank, world)
+        fused = guarded("fused_steps", fused_leg, device, rank, world, B)
+        scaled = guarded("scaled_topology", scaled_leg, device, rank, world)
+        marl_env = guarded("pymarl_env", marl_env_leg, device, rank, world)
     mappo = None
     ippo = None
     mappo_scaled = None
     if not args.no_mappo:
-        mappo = mappo_leg(device, rank, world, args.mappo_envs)
-        ippo = ippo_leg(device, rank, world)
-        mappo_scaled = ippo_leg(device, rank, world, algorithm="mappo")
+        mappo = guarded("mappo", mappo_leg, device, rank, world, args.mappo_envs)
+        ippo = guarded("ippo_scaled", ippo_leg, device, rank, world)
+        mappo_scaled = guarded("mappo_scaled", ippo_leg, device, rank, world, algorithm="mappo")
 
     if rank == 0:
         agent_steps = world * B * n * args.steps
@@ -526,7 +544,7 @@ def main():
                          "bytes_per_launch": bytes_launch, "avg_launch_us": launch_s * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline)
         if scale is not None:
             sb, sk, se, sd = scale
             s_bytes = algorithmic_bytes_per_env_step(n, record_bytes) * sb
