@@ -310,11 +310,16 @@ int em_rollout_index(const em_rollout *ro, int32_t t, const uint64_t *active, co
  * of the step (noise = pre-drawn eps [E][n+1] aligned with the entries, or NULL for the in-kernel
  * Philox/Box-Muller stream addressed by (seed; env_offset+env, episode, rng_step, agent); explore == 0 takes
  * a = mu and log-prob 0), stores action/log-prob, writes
- * the env actions placement/resource [n_envs][n_nodes] and the critic values. */
+ * the env actions placement/resource [n_envs][n_nodes] and the critic values.  critic == NULL skips the value part
+ * (a caller that runs em_value_step itself, e.g. on a second stream beside the environment step). */
 int em_policy_step(const em_rollout *ro, int32_t t, const em_mlp3 *actor, const float *log_std, const em_mlp3 *critic,
                    float value_norm_mean, float value_norm_var, const float *noise, int explore, uint64_t seed,
                    uint32_t episode, uint32_t rng_step, uint64_t env_offset, int32_t *placement, float *resource,
                    void *stream);
+/* MAPPO.get_values for step t alone (mappo_algorithm.py:226-239): the critic forward over the step's compact states,
+ * results into st_value and value_tb[t].  Needs em_rollout_index of step t; nothing before em_gae reads its output. */
+int em_value_step(const em_rollout *ro, int32_t t, const em_mlp3 *critic, float value_norm_mean, float value_norm_var,
+                  void *stream);
 
 /* MAPPO.compute_gae (mappo_algorithm.py:241-262) for every environment's segment of the transition
  * list (next_value = 0 per segment, :284), float64 recursion, results rounded to float32 into

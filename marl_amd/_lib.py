@@ -145,6 +145,8 @@ def lib() -> C.CDLL:
     L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
                                  C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    L.em_value_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
+    L.em_value_step.restype = C.c_int
     f32, f64 = C.c_float, C.c_double
     L.em_gae.argtypes = [C.POINTER(EmRollout), f64, f64, vp, i64, vp, vp]
     L.em_ppo_slab_floats.argtypes = [C.c_int32, C.c_int32, i32]

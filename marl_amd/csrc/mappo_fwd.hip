@@ -537,6 +537,23 @@ int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, co
     return em::hip_check(hipGetLastError(), "rollout index/compact launch");
 }
 
+int em_value_step(const em_rollout* ro, int32_t t, const em_mlp3* critic, float value_norm_mean, float value_norm_var, void* stream)
+{
+    if (!ro) return em::fail(EM_ERR_INVALID, "em_value_step: null argument");
+    if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_value_step: step outside the horizon");
+    int rc = check_net(critic);
+    if (rc) return rc;
+    const int n = ro->n_nodes;
+    if (critic->in_dim != n * (n + 4) || critic->out_dim != 1)
+        return em::fail(EM_ERR_INVALID, "em_value_step: network shape does not match n_nodes=%d", n);
+    FwdArgs fc;
+    std::memset(&fc, 0, sizeof fc);
+    fc.net = *critic; fc.x = ro->st_state; fc.ldx = (int64_t)n * (n + 4); fc.dyn = ro->counters + 4 * t + 2;
+    fc.st_value = ro->st_value; fc.st_env = ro->st_env; fc.value_tb = ro->value_tb + (int64_t)t * ro->n_envs;
+    fc.norm_mean = value_norm_mean; fc.norm_scale = sqrtf(value_norm_var + 1e-8f);
+    return launch_fwd<2>(fc, ro->n_envs, (hipStream_t)stream);
+}
+
 int em_policy_step(const em_rollout* ro, int32_t t, const em_mlp3* actor, const float* log_std, const em_mlp3* critic,
                    float value_norm_mean, float value_norm_var, const float* noise, int explore, uint64_t seed,
                    uint32_t episode, uint32_t rng_step, uint64_t env_offset, int32_t* placement, float* resource, void* stream)
@@ -545,12 +562,16 @@ int em_policy_step(const em_rollout* ro, int32_t t, const em_mlp3* actor, const 
     if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_policy_step: step outside the horizon");
     int rc = check_net(actor);
     if (rc) return rc;
-    rc = check_net(critic);
-    if (rc) return rc;
     const int n = ro->n_nodes;
-    if (actor->in_dim != n + 4 || actor->out_dim != n + 1 || critic->in_dim != n * (n + 4) || critic->out_dim != 1)
+    if (actor->in_dim != n + 4 || actor->out_dim != n + 1)
         return em::fail(EM_ERR_INVALID, "em_policy_step: network shapes do not match n_nodes=%d", n);
     if (n + 1 > 16) return em::fail(EM_ERR_INVALID, "em_policy_step: n_nodes must be <= 15 for the fused policy epilogue");
+    if (critic) {                                            // validated before anything is launched
+        rc = check_net(critic);
+        if (rc) return rc;
+        if (critic->in_dim != n * (n + 4) || critic->out_dim != 1)
+            return em::fail(EM_ERR_INVALID, "em_policy_step: network shapes do not match n_nodes=%d", n);
+    }
     hipStream_t s = (hipStream_t)stream;
     FwdArgs fa;
     std::memset(&fa, 0, sizeof fa);
@@ -561,13 +582,8 @@ int em_policy_step(const em_rollout* ro, int32_t t, const em_mlp3* actor, const 
     fa.seed_lo = (uint32_t)seed; fa.seed_hi = (uint32_t)(seed >> 32); fa.episode = episode; fa.step = rng_step;
     fa.env_offset = (uint32_t)env_offset;
     rc = launch_fwd<1>(fa, ro->n_envs * n, s);
-    if (rc) return rc;
-    FwdArgs fc;
-    std::memset(&fc, 0, sizeof fc);
-    fc.net = *critic; fc.x = ro->st_state; fc.ldx = (int64_t)n * (n + 4); fc.dyn = ro->counters + 4 * t + 2;
-    fc.st_value = ro->st_value; fc.st_env = ro->st_env; fc.value_tb = ro->value_tb + (int64_t)t * ro->n_envs;
-    fc.norm_mean = value_norm_mean; fc.norm_scale = sqrtf(value_norm_var + 1e-8f);
-    return launch_fwd<2>(fc, ro->n_envs, s);
+    if (rc || !critic) return rc;
+    return em_value_step(ro, t, critic, value_norm_mean, value_norm_var, stream);
 }
 
 }  // extern "C"

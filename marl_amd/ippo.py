@@ -103,25 +103,54 @@ class IPPO:
         self.fwd_split = self.split          # workgroups per network in the rollout forwards (rows are independent)
         self._slab_a = self._slab_c = None
         self.last_update = {}
+        # the value forward of a step feeds nothing before GAE: during a recorded rollout the trainer lets it run on a
+        # side stream beside the policy forward and the environment step (overlap_value); join_value() orders the main
+        # stream behind it again (called before the next step's index overwrites group_off/perm, and by update())
+        self.overlap_value = False
+        self._side = self._ev_idx = self._ev_val = None
+        self._value_pending = False
+
+    def _value_async(self, fn):
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._ev_idx, self._ev_val = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_idx.record(main)                       # everything queued so far: this step's index kernels
+        self._side.wait_event(self._ev_idx)
+        with torch.cuda.stream(self._side):
+            fn()
+            self._ev_val.record(self._side)
+        self._value_pending = True
+
+    def join_value(self):
+        if self._value_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_val)
+            self._value_pending = False
 
     # -- rollout: MAPPOTrainer.train_episode steps 199-219 for all environments ----------------------------------------
     def record_and_act(self, t, env: ScaledEdgeSimGym, placement, resource, explore=True, noise=None, seed=0, episode=0,
                        env_offset=0, rng_step=None):
         ro = self.buffer
         tt = ro.t
+        self.join_value()
         with torch.cuda.device(self.device):
             _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, self.G, env.n_pending.data_ptr(),
                                                  env.pend_decider.data_ptr(), env.pend_obs.data_ptr(), _stream(self.device)),
                        "ems_rollout_index")
+        value = lambda: gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.fwd_split)  # noqa: E731
+        if self.overlap_value:
+            self._value_async(value)
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
                     tt["ent_action"], tt["ent_logp"], tt["group_off"], tt["perm"], self.fwd_split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
-        gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.fwd_split)
+        if not self.overlap_value:
+            value()
         ro.steps_recorded = t + 1
 
     # -- update ----------------------------------------------------------------------------------------------------------
     def update(self):
         ro = self.buffer
+        self.join_value()
         if ro.steps_recorded == 0:
             return {}
         E = ro.total()
@@ -229,6 +258,7 @@ class IPPOTrainer:
         self._train_storage = self.algo.buffer
         self._scratch = None
         self.policy_episode = 0
+        self.overlap_value = True      # value forward on a side stream during recorded rollouts (identical results)
         if verbose and self.rank == 0:
             kind = {"shared": "shared-parameter PPO", "mappo": "MAPPO (shared actor, central critic)"}.get(
                 algorithm, f"IPPO ({self.D} independent learners)")
@@ -250,6 +280,7 @@ class IPPOTrainer:
         env.reset()
         self.policy_episode += 1
         total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        a.overlap_value = bool(record_buffer) and self.overlap_value
         try:
             for t in range(T):
                 slot = t if record_buffer else 0
@@ -264,6 +295,8 @@ class IPPOTrainer:
                     env.step(self.placement, self.resource, by_slot=True)
                     total_reward += env.reward
         finally:
+            a.overlap_value = False
+            a.join_value()
             a.buffer = self._train_storage
         if record_buffer:
             total_reward = ro.t["reward_tb"][:T].sum(dim=0)

@@ -242,6 +242,17 @@ class MAPPO:
         self._slab_a = self._slab_c = None
         self.grad_norms = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.last_update = {}
+        # nothing before GAE reads the critic's values: during a recorded rollout the trainer lets the value forward run on
+        # a side stream beside the policy forward and the environment step (overlap_value); join_value() orders the main
+        # stream behind it again (end of the episode, compute_gae)
+        self.overlap_value = False
+        self._side = self._ev_idx = self._ev_val = None
+        self._value_pending = False
+
+    def join_value(self):
+        if self._value_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_val)
+            self._value_pending = False
 
     # -- rollout side ----------------------------------------------------------------------------------
     def _norm(self):
@@ -258,8 +269,21 @@ class MAPPO:
                        "em_rollout_index")
             a_net, c_net = self.actor.net(), self.critic.net()
             mean, var = self._norm_cached
+            fused_critic = C.byref(c_net)
+            if self.overlap_value:
+                main = torch.cuda.current_stream(self.device)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.device)
+                    self._ev_idx, self._ev_val = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_idx.record(main)                   # this step's index kernels
+                self._side.wait_event(self._ev_idx)
+                _lib.check(self._L.em_value_step(C.byref(ro.struct), t, C.byref(c_net), mean, var, int(self._side.cuda_stream)),
+                           "em_value_step")
+                self._ev_val.record(self._side)
+                self._value_pending = True
+                fused_critic = None
             _lib.check(self._L.em_policy_step(C.byref(ro.struct), t, C.byref(a_net), self.actor.log_std.data_ptr(),
-                                              C.byref(c_net), mean, var, noise.data_ptr() if noise is not None else None,
+                                              fused_critic, mean, var, noise.data_ptr() if noise is not None else None,
                                               1 if explore else 0, int(seed) & (2**64 - 1), int(episode),
                                               int(t if rng_step is None else rng_step), int(env_offset),
                                               placement_out.data_ptr(), resource_out.data_ptr(), s), "em_policy_step")
@@ -272,6 +296,7 @@ class MAPPO:
     # -- GAE (mappo_algorithm.py:241-262) --------------------------------------------------------------
     def compute_gae(self):
         ro = self.buffer
+        self.join_value()
         with torch.cuda.device(self.device):
             _lib.check(self._L.em_gae(C.byref(ro.struct), float(self.gamma), float(self.gae_lambda),
                                       self._gae_partials.data_ptr(), self._gae_partials.numel(), self.moments.data_ptr(),

@@ -70,24 +70,34 @@ class ScaledMAPPO(IPPO):
                        rng_step=None):
         ro = self.buffer
         tt, dev, D = ro.t, self.device, self.D
+        self.join_value()
         with torch.cuda.device(dev):
             _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, D, env.n_pending.data_ptr(), env.pend_decider.data_ptr(),
                                                  env.pend_obs.data_ptr(), _stream(dev)), "ems_rollout_index")
+        cc = self.critic.struct()
+        B = ro.n_envs
+        part = self._partials(ro.capacity_entries)
+
+        def value():
+            with torch.cuda.device(dev):
+                _lib.check(self._L.em_cc_forward(C.byref(cc), tt["ent_obs"].data_ptr(), tt["group_off"].data_ptr(), tt["perm"].data_ptr(),
+                                                 self.cc_split, part.data_ptr(), B, tt["k_tb"][t].data_ptr(),
+                                                 tt["first_tb"][t].data_ptr(), 0.0, 1.0, tt["value_tb"][t].data_ptr(), _stream(dev)),
+                           "em_cc_forward")
+
+        if self.overlap_value:
+            self._value_async(value)
         # shared actor: the step as one group ({0, entries} sits behind the per-decider offsets), same permutation
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
                     tt["ent_action"], tt["ent_logp"], tt["group_off"][D + 1:], tt["perm"], self.split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
-        cc = self.critic.struct()
-        B = ro.n_envs
-        with torch.cuda.device(dev):
-            _lib.check(self._L.em_cc_forward(C.byref(cc), tt["ent_obs"].data_ptr(), tt["group_off"].data_ptr(), tt["perm"].data_ptr(),
-                                             self.cc_split, self._partials(ro.capacity_entries).data_ptr(), B,
-                                             tt["k_tb"][t].data_ptr(), tt["first_tb"][t].data_ptr(), 0.0, 1.0,
-                                             tt["value_tb"][t].data_ptr(), _stream(dev)), "em_cc_forward")
+        if not self.overlap_value:
+            value()
         ro.steps_recorded = t + 1
 
     def update(self):
         ro = self.buffer
+        self.join_value()
         if ro.steps_recorded == 0:
             return {}
         E = ro.total()

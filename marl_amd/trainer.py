@@ -55,6 +55,7 @@ class MAPPOTrainer:
         self._train_storage = self.mappo.buffer
         self._scratch_storage = None
         self.policy_episode = 0
+        self.overlap_value = True      # value forward on a side stream during recorded rollouts (identical results)
         if verbose and self.rank == 0:
             print(f"[OK] MAPPO (MI355X) initialised: obs {self.obs_dim}, state {self.state_dim}, action {self.action_dim}, "
                   f"agents {self.n_agents}, envs/GPU {self.n_envs}, device {self.device}")
@@ -85,6 +86,7 @@ class MAPPOTrainer:
             m.begin_rollout()
         self.policy_episode += 1
         total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        m.overlap_value = bool(record_buffer) and self.overlap_value
         try:
             for t in range(T):
                 slot = base + t if record_buffer else 0
@@ -98,6 +100,8 @@ class MAPPOTrainer:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None)
                     total_reward += env.reward
         finally:
+            m.overlap_value = False
+            m.join_value()
             m.buffer = self._train_storage
         if record_buffer:
             total_reward = ro.t["reward_tb"][base:base + T].sum(dim=0)
