@@ -188,6 +188,7 @@ class RolloutStorage:
             reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), value_tb=z((T, B), f32), k_tb=z((T, B), u8),
             first_tb=z((T, B), i32), srow=z(B, i32), scan_scratch=z((B + 63) // 64, torch.int64), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32))
         self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() for v in self.t.values()])
+        self.ref = C.byref(self.struct)
         self.steps_recorded = 0
 
     def clear(self):
@@ -263,35 +264,38 @@ class MAPPO:
         """Steps 199-219 of MAPPOTrainer.train_episode for all environments: index the acting agents, sample
         their actions, format the env actions and evaluate the critic on the pre-step state."""
         ro = self.buffer
+        a_ref, c_ref, log_std = self._nets_cached          # structs of begin_rollout: parameters live in one flat buffer
+        mean, var = self._norm_cached
+        L = self._L
         with torch.cuda.device(self.device):
-            s = _stream(self.device)
-            _lib.check(self._L.em_rollout_index(C.byref(ro.struct), t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s),
-                       "em_rollout_index")
-            a_net, c_net = self.actor.net(), self.critic.net()
-            mean, var = self._norm_cached
-            fused_critic = C.byref(c_net)
+            main = torch.cuda.current_stream(self.device)
+            s = int(main.cuda_stream)
+            _lib.check(L.em_rollout_index(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s), "em_rollout_index")
+            fused_critic = c_ref
             if self.overlap_value:
-                main = torch.cuda.current_stream(self.device)
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
                     self._ev_idx, self._ev_val = torch.cuda.Event(), torch.cuda.Event()
                 self._ev_idx.record(main)                   # this step's index kernels
                 self._side.wait_event(self._ev_idx)
-                _lib.check(self._L.em_value_step(C.byref(ro.struct), t, C.byref(c_net), mean, var, int(self._side.cuda_stream)),
-                           "em_value_step")
+                _lib.check(L.em_value_step(ro.ref, t, c_ref, mean, var, int(self._side.cuda_stream)), "em_value_step")
                 self._ev_val.record(self._side)
                 self._value_pending = True
                 fused_critic = None
-            _lib.check(self._L.em_policy_step(C.byref(ro.struct), t, C.byref(a_net), self.actor.log_std.data_ptr(),
-                                              fused_critic, mean, var, noise.data_ptr() if noise is not None else None,
-                                              1 if explore else 0, int(seed) & (2**64 - 1), int(episode),
-                                              int(t if rng_step is None else rng_step), int(env_offset),
-                                              placement_out.data_ptr(), resource_out.data_ptr(), s), "em_policy_step")
+            _lib.check(L.em_policy_step(ro.ref, t, a_ref, log_std, fused_critic, mean, var,
+                                        noise.data_ptr() if noise is not None else None, 1 if explore else 0,
+                                        int(seed) & (2**64 - 1), int(episode), int(t if rng_step is None else rng_step),
+                                        int(env_offset), placement_out.data_ptr(), resource_out.data_ptr(), s), "em_policy_step")
         ro.steps_recorded = t + 1
 
     def begin_rollout(self):
         self.buffer.clear()
         self._norm_cached = self._norm()
+        self._cache_nets()
+
+    def _cache_nets(self):
+        self._net_structs = (self.actor.net(), self.critic.net())          # keeps the ctypes structs alive
+        self._nets_cached = (C.byref(self._net_structs[0]), C.byref(self._net_structs[1]), self.actor.log_std.data_ptr())
 
     # -- GAE (mappo_algorithm.py:241-262) --------------------------------------------------------------
     def compute_gae(self):

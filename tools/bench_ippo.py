@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--shared", action="store_true")
     ap.add_argument("--fwd-split", type=int, default=0)
@@ -23,6 +24,7 @@ def main():
     cfg = dict(SCALED_ENV_CONFIG)
     cfg["episode_length"] = a.horizon
     tr = IPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=a.envs, algorithm="shared" if a.shared else a.algorithm, verbose=False)
+    tr.overlap_value = not a.no_overlap
     if a.fwd_split:
         tr.algo.fwd_split = a.fwd_split
     if a.bwd_split:

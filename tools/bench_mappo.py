@@ -14,11 +14,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--horizon", type=int, default=1000)
     a = ap.parse_args()
     cfg = dict(ENV_CONFIG)
     cfg["episode_length"] = a.horizon
     tr = MAPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=a.envs, verbose=False)
+    tr.overlap_value = not a.no_overlap
     for it in range(a.iters + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
