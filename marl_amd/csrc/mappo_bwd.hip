@@ -114,7 +114,12 @@ struct BwdArgs {
     float vcoef, norm_mean, norm_scale;
 };
 
-template <int KU, bool ACTOR>
+// STAGE (wide inputs with contiguous, 16-byte aligned rows of K1 % 4 == 0 floats: the 140-wide critic): a tile's 16 input rows
+// are one contiguous span; it is copied ONCE, global -> LDS with no register in between (global_load_lds_dwordx4), into a
+// per-wavefront double buffer while the previous tile computes.  The forward reads its x fragments from that copy and the
+// dW1 products read the same copy again, where the register version fetched 4 x KU dependent scalars per tile from
+// global memory a second time; with one wavefront per SIMD nothing else hides either latency.
+template <int KU, bool ACTOR, bool STAGE = false>
 __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -127,6 +132,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
     float* W2s = W1s + HID * S1;                      // [64][S2]
     float* W3s = W2s + HID * S2;                      // [16][S2] (rows >= O are zero)
     float* scr = W3s + 16 * S2 + wave * (HID * TS);   // per-wavefront transpose scratch [64][TS]
+    constexpr int NI = (4 * K1P + 63) / 64;           // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
+    constexpr int XBUF = NI * 256;                    // floats per staged tile, whole copies (the tail of the last is slack)
+    float* xs = W3s + 16 * S2 + 4 * (HID * TS) + wave * (2 * XBUF);
 
     for (int i = threadIdx.x; i < HID * K1P; i += 256) {
         const int r = i / K1P, k = i - r * K1P;
@@ -206,10 +214,35 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
         if (t0 < n_tiles) load_x(t0, xb);
     }
+    // STAGE: asynchronous copy of a tile into one half of this wavefront's double buffer.  Lanes past the tile's last
+    // valid float4 re-read its first one (always valid) into slack or into rows that every consumer masks.
+    auto stage = [&](int64_t tile_, float* dst) {
+        const float* gt = a.x + tile_ * 16 * (int64_t)K1;
+        const int64_t rows_left = a.n_rows - tile_ * 16;
+        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * (K1 >> 2);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = lane + 64 * j;
+            const float* src = gt + 4 * (idx < nvv ? idx : 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + j * 256), 16, 0, 0);
+        }
+    };
+    int cur = 0;
+    if constexpr (STAGE) {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+        if (t0 < n_tiles) stage(t0, xs);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;
         const bool valid = row < a.n_rows;
-        if constexpr (!PREFETCH) load_x(tile, xb);
+        const float* xt = xs + cur * XBUF;            // STAGE: this tile, [16][K1] packed
+        if constexpr (STAGE) {
+            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF);
+        } else if constexpr (!PREFETCH) load_x(tile, xb);
         // loss inputs of this tile: issued now, needed after the forward pass
         float p_act[4] = {0.f, 0.f, 0.f, 0.f}, p_adv = 0.0f, p_old = 0.0f;
         int p_k = 0;
@@ -229,12 +262,27 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         f32x4 h1[4], h2[4], y;
 #pragma unroll
         for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
+        if constexpr (STAGE) {
 #pragma unroll
-        for (int s = 0; s < KU * 4; ++s) {
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+            for (int u = 0; u < KU; ++u) {
+                const int k0 = 16 * u + 4 * q;
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 < K1) xv = *reinterpret_cast<const float4*>(xt + c * K1 + k0);      // K1 % 4 == 0: whole or nothing
+                const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h1[t], 0, 0, 0);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k0 + r], xa[r], h1[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KU * 4; ++s) {
+                const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h1[t], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -400,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
-            const float* xrow = a.x + (rb < a.n_rows ? rb : 0) * a.ldx;
+            const float* xrow = STAGE ? xt + (4 * s + q) * K1 : a.x + (rb < a.n_rows ? rb : 0) * a.ldx;
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int i = 16 * u + c;
@@ -409,6 +457,12 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
                 for (int t = 0; t < 4; ++t)
                     gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
             }
+        }
+        if constexpr (STAGE) {                        // the next tile has landed; this tile's half may be overwritten
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
         }
     }
 
@@ -533,22 +587,33 @@ int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
 {
     const int ku = (ba.net.in_dim + 15) / 16;
     const int s1 = ((ku * 16 + 2) | 2);
-    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 4 * HID * TS);
+    // staged input tiles (see mlp3_bwd_kernel): wide inputs whose 16-row tiles are contiguous, aligned spans
+    const bool stage = ku > 4 && ba.ldx == ba.net.in_dim && (ba.net.in_dim & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(ba.x) & 15) == 0;
+    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 4 * HID * TS +
+                                        (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
     const dim3 grid((unsigned)(n_waves / 4)), block(256);
-#define EM_BWD(KU_)                                                                                               \
-    case KU_: {                                                                                                   \
+#define EM_BWD_ONE(KU_, STAGE_)                                                                                   \
+    {                                                                                                             \
         if (lds > 64 * 1024) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute((const void*)mlp3_bwd_kernel<KU_, ACTOR>,                           \
+            hipError_t e = hipFuncSetAttribute((const void*)mlp3_bwd_kernel<KU_, ACTOR, STAGE_>,                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
             if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                   \
         }                                                                                                         \
-        hipLaunchKernelGGL((mlp3_bwd_kernel<KU_, ACTOR>), grid, block, lds, s, ba);                               \
+        hipLaunchKernelGGL((mlp3_bwd_kernel<KU_, ACTOR, STAGE_>), grid, block, lds, s, ba);                       \
+    }
+#define EM_BWD(KU_)                                                                                               \
+    case KU_: {                                                                                                   \
+        if constexpr (KU_ > 4) {                                                                                  \
+            if (stage) EM_BWD_ONE(KU_, true) else EM_BWD_ONE(KU_, false)                                          \
+        } else EM_BWD_ONE(KU_, false)                                                                             \
     } break
     switch (ku) {
         EM_BWD(1); EM_BWD(2); EM_BWD(3); EM_BWD(4); EM_BWD(5); EM_BWD(6); EM_BWD(7); EM_BWD(8); EM_BWD(9);
         default: return em::fail(EM_ERR_INVALID, "mlp3 backward: unsupported in_dim");
     }
 #undef EM_BWD
+#undef EM_BWD_ONE
     return em::hip_check(hipGetLastError(), "mlp3_bwd_kernel launch");
 }
 
