@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
 }
 
 // fused forward-recompute + loss + backward for the rows of one group (mlp3_bwd_kernel generalised)
-template <int KU, int OT, bool ACTOR>
+// STAGE (rows of K1 % 4 == 0 floats, 16-byte aligned): a tile's 16 input rows are copied ONCE, global -> LDS with no register
+// in between (global_load_lds_dwordx4), into a per-wavefront double buffer while the previous tile computes; the forward
+// takes its x fragments from the copy and the dW1 products read it again (the register version gathered 4 x KU dependent
+// scalars per tile from global memory a second time, through the permutation).
+template <int KU, int OT, bool ACTOR, bool STAGE = false>
 __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -308,6 +312,9 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
     // reciprocal per element and tile: 2*sd^2 and 1/sd^2 (same expressions, so the same bits as evaluating them in place)
     float* den_t = lds + L::END + 4 * (HID * TS);
     float* iv_t = den_t + 16 * OT;
+    constexpr int NI = (4 * L::K1P + 63) / 64;        // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
+    constexpr int XBUF = NI * 256;                    // floats per staged tile (the tail of the last copy is slack)
+    float* xs = iv_t + 16 * OT + wave * (2 * XBUF);
     __syncthreads();
     if constexpr (ACTOR) {
         if (threadIdx.x < 16 * OT) {
@@ -350,12 +357,50 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         for (int o = 0; o < O; ++o) ent_row += 0.5f + HALF_LOG_2PI + lds[L::LS + o];            // Normal.entropy summed
     }
 
-    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
+    // STAGE: asynchronous copy of a tile, [16][K1] packed.  Lanes past the tile's last valid float4 re-read its first row
+    // (always valid) into slack or into rows that every consumer masks.
+    auto stage = [&](int64_t tile_, float* dst) {
+        const int rv = K1 >> 2;
+        const int64_t p0 = r0 + tile_ * 16, rows_left = n_rows - tile_ * 16;
+        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * rv;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = lane + 64 * j;
+            const bool ok = idx < nvv;
+            const int rw = ok ? idx / rv : 0, v = ok ? idx - rw * rv : 0;
+            const int64_t gr = a.perm ? (int64_t)a.perm[p0 + rw] : p0 + rw;
+            const float* src = a.x + gr * a.ldx + 4 * v;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + j * 256), 16, 0, 0);
+        }
+    };
+    int cur = 0;
+    if constexpr (STAGE) {
+        const int64_t t0 = (int64_t)part * 4 + wave;
+        if (t0 < n_tiles) stage(t0, xs);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int64_t tile_stride = (int64_t)a.split * 4;
+    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;
         const bool valid = row < n_rows;
         const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
+        const float* xt = xs + cur * XBUF;
         float xb[KU * 4];
-        load_x_frag<KU>(a, grow, valid, q, xb);
+        if constexpr (STAGE) {
+            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k0 = 16 * u + 4 * q;
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid && k0 < K1) xv = *reinterpret_cast<const float4*>(xt + c * K1 + k0);   // K1 % 4 == 0: whole or nothing
+                xb[u * 4 + 0] = xv.x; xb[u * 4 + 1] = xv.y; xb[u * 4 + 2] = xv.z; xb[u * 4 + 3] = xv.w;
+            }
+        } else {
+            load_x_frag<KU>(a, grow, valid, q, xb);
+        }
         float p_adv = 0.0f, p_old = 0.0f, p_ret = 0.0f;
         if (valid) {
             if constexpr (ACTOR) { p_adv = a.adv[grow]; p_old = a.old_logp[grow]; }
@@ -506,8 +551,13 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
             const bool vb = rb < n_rows;
-            const int64_t gb = vb ? (a.perm ? (int64_t)a.perm[r0 + rb] : r0 + rb) : 0;
-            const float* xrow = a.x + gb * a.ldx;
+            const float* xrow;
+            if constexpr (STAGE) {
+                xrow = xt + (4 * s + q) * K1;
+            } else {
+                const int64_t gb = vb ? (a.perm ? (int64_t)a.perm[r0 + rb] : r0 + rb) : 0;
+                xrow = a.x + gb * a.ldx;
+            }
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int i = 16 * u + c;
@@ -516,6 +566,12 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 for (int t = 0; t < 4; ++t)
                     gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
             }
+        }
+        if constexpr (STAGE) {                        // the next tile has landed; this tile's half may be overwritten
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
         }
     }
 
@@ -700,10 +756,11 @@ int check_gnet(const em_gmlp* net)
     return EM_OK;
 }
 
-size_t lds_bytes(int ku, int ot, bool bwd)
+size_t lds_bytes(int ku, int ot, bool bwd, bool stage = false)
 {
     const int s1 = (ku * 16 + 2) | 2;
-    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 0));
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 0) +
+                            (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
 }
 
 template <typename K>
@@ -742,12 +799,18 @@ int launch_gbwd(const GArgs& ga, hipStream_t s)
 {
     const int ot = (ga.net.out_dim + 15) / 16;
     const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(256);
+    // staged input tiles (see gmlp_bwd_kernel): rows of a multiple of four floats on 16-byte boundaries
+    const bool stage = (ga.net.in_dim & 3) == 0 && (ga.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(ga.x) & 15) == 0;
+#define EM_GB_ONE(OT_, STAGE_)                                                                        \
+    {                                                                                                 \
+        const size_t lds = lds_bytes(5, OT_, true, STAGE_);                                           \
+        const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_>, lds);                          \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_>), grid, block, lds, s, ga);        \
+    }
 #define EM_GB(OT_)                                                                                    \
     case OT_: {                                                                                       \
-        const size_t lds = lds_bytes(5, OT_, true);                                                   \
-        const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR>, lds);                                  \
-        if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR>), grid, block, lds, s, ga);                \
+        if (stage) EM_GB_ONE(OT_, true) else EM_GB_ONE(OT_, false)                                    \
     } break
     if constexpr (ACTOR) {
         switch (ot) {
@@ -761,6 +824,7 @@ int launch_gbwd(const GArgs& ga, hipStream_t s)
         }
     }
 #undef EM_GB
+#undef EM_GB_ONE
     return em::hip_check(hipGetLastError(), "gmlp_bwd_kernel launch");
 }
 
