@@ -485,8 +485,11 @@ int launch_fwd(const FwdArgs& fa, int64_t max_rows, hipStream_t s)
     const int ku = (fa.net.in_dim + 15) / 16;
     int64_t tiles = (max_rows + 15) / 16;
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 256) blocks = 256;       // persistent, one workgroup per CU: the weights are staged once per workgroup
-    if (blocks < 1) blocks = 1;           // and each wavefront keeps its fragments while it strides over tiles
+    // persistent workgroups: the weights are staged once per workgroup and each wavefront strides over tiles.  Narrow
+    // networks fit two wavefronts per SIMD (<= 256 VGPRs, 20 KB of LDS): two workgroups per CU hide each other's latency
+    const int64_t cap = ku <= 4 ? 512 : 256;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks), block(256);
     const int s1 = (ku * 16 + 2) | 2;
     const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * 66 + 16 * 66);

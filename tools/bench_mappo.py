@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from marl_amd.config import ENV_CONFIG  # noqa: E402
 from marl_amd.trainer import MAPPOTrainer  # noqa: E402
 
