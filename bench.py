@@ -86,6 +86,25 @@ def cpu_baseline(seconds_target: float = 12.0) -> dict:
         out["mappo_loop"] = mappo_loop_oracle.time_loop(8.0)
     except Exception as e:  # pragma: no cover - informational only
         out["mappo_loop_error"] = repr(e)
+    # "whole host" figure: one environment per core, P independent processes of the same restatement
+    try:
+        import subprocess
+        try:
+            P = len(os.sched_getaffinity(0))
+        except AttributeError:
+            P = os.cpu_count() or 1
+        P = max(1, min(P, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+        env_ = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        t1 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_timing", "5.0", str(i)], cwd=ROOT, env=env_,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
+        res = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t1
+        out["whole_host"] = {"value": sum(r["steps"] * r["n"] / r["seconds"] for r in res), "unit": "agent-steps/s",
+                             "processes": P, "sample": f"{P} processes x 5.0 s, one environment each, same restatement",
+                             "wall_s": wall}
+    except Exception as e:  # pragma: no cover - informational only
+        out["whole_host_error"] = repr(e)
     out["host"] = {"nproc": os.cpu_count(), "cpu": _cpu_model()}
     return out
 
