@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         __syncthreads();
     }
 
-    f32x4 gW1[4][KU], gW2[4][4], gW3[OT][4], gb1[4], gb2[4], gb3[OT], gls[OT];
+    f32x4 gW1[4][KU], gW2[4][4], gW3[OT][4], gb3[OT], gls[OT];
+    float gb1_l = 0.0f, gb2_l = 0.0f;                  // bias gradients of feature `lane`: row sums of the transposed dZ tiles
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -333,7 +334,6 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         for (int u = 0; u < KU; ++u) gW1[t][u] = zero4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) gW2[t][u] = zero4;
-        gb1[t] = zero4; gb2[t] = zero4;
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
@@ -484,7 +484,6 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
             dz1[t] = zero4;
-            gb2[t] += dz2[t];
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
@@ -497,12 +496,12 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
-            gb1[t] += dz1[t];
         }
 
         // ---- weight gradients: reduction over the 16 batch rows of the tile ------------------------------------
         float tr_a[4][4], tr_b[4][4];
-        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4]) {
+        // rowsum: += sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
+        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4], float* rowsum) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -513,11 +512,17 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) out[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
+            if (rowsum) {
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) { p0 += scr[lane * TS + j]; p1 += scr[lane * TS + j + 1]; }
+                *rowsum += p0 + p1;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
-        transpose64(h2, tr_b);
+        transpose64(h2, tr_b, nullptr);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
             float tr_y[4];
@@ -536,8 +541,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     gW3[ot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[ot][t], 0, 0, 0);
         }
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
-        transpose64(dz2, tr_a);
-        transpose64(h1, tr_b);
+        transpose64(dz2, tr_a, &gb2_l);
+        transpose64(h1, tr_b, nullptr);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 for (int t1 = 0; t1 < 4; ++t1)
                     gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
-        transpose64(dz1, tr_a);
+        transpose64(dz1, tr_a, &gb1_l);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
@@ -605,11 +610,6 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                gb1[t][r] += __shfl_xor(gb1[t][r], m);
-                gb2[t][r] += __shfl_xor(gb2[t][r], m);
-            }
-#pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
                 gb3[ot][r] += __shfl_xor(gb3[ot][r], m);
                 gls[ot][r] += __shfl_xor(gls[ot][r], m);
@@ -622,14 +622,9 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         aux_sum += __shfl_xor(aux_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
+    out[o_b1 + lane] = gb1_l;
+    out[o_b2 + lane] = gb2_l;
     if (c == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[o_b1 + 16 * t + 4 * q + r] = gb1[t][r];
-                out[o_b2 + 16 * t + 4 * q + r] = gb2[t][r];
-            }
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
 #pragma unroll

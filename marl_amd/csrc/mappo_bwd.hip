@@ -119,8 +119,12 @@ struct BwdArgs {
 // per-wavefront double buffer while the previous tile computes.  The forward reads its x fragments from that copy and the
 // dW1 products read the same copy again, where the register version fetched 4 x KU dependent scalars per tile from
 // global memory a second time; with one wavefront per SIMD nothing else hides either latency.
+// Narrow inputs (KU == 1: the 14-wide actor) are compiled for TWO workgroups per CU (<= 256 registers): the loss epilogue,
+// the LDS transposes and the accumulator drains of one wavefront then run under the other wavefront's MFMAs.  To fit, the
+// layer biases are re-read from LDS per tile instead of living in 32 registers, and the bias gradients are row sums of the
+// transposed dZ tiles that the weight-gradient products stage in LDS anyway (one register per lane instead of 32).
 template <int KU, bool ACTOR, bool STAGE = false>
-__global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
+__global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const BwdArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,10 +135,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
     float* W1s = lds;                                 // [64][S1]
     float* W2s = W1s + HID * S1;                      // [64][S2]
     float* W3s = W2s + HID * S2;                      // [16][S2] (rows >= O are zero)
-    float* scr = W3s + 16 * S2 + wave * (HID * TS);   // per-wavefront transpose scratch [64][TS]
+    float* Bs = W3s + 16 * S2;                        // [2][64] biases of layers 1 and 2
+    float* scr = Bs + 2 * HID + wave * (HID * TS);    // per-wavefront transpose scratch [64][TS]
     constexpr int NI = (4 * K1P + 63) / 64;           // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
     constexpr int XBUF = NI * 256;                    // floats per staged tile, whole copies (the tail of the last is slack)
-    float* xs = W3s + 16 * S2 + 4 * (HID * TS) + wave * (2 * XBUF);
+    float* xs = Bs + 2 * HID + 4 * (HID * TS) + wave * (2 * XBUF);
 
     for (int i = threadIdx.x; i < HID * K1P; i += 256) {
         const int r = i / K1P, k = i - r * K1P;
@@ -142,21 +147,16 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
     }
     for (int i = threadIdx.x; i < HID * HID; i += 256) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
     for (int i = threadIdx.x; i < 16 * HID; i += 256) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
+    if (threadIdx.x < 2 * HID) Bs[threadIdx.x] = threadIdx.x < HID ? a.net.b1[threadIdx.x] : a.net.b2[threadIdx.x - HID];
     __syncthreads();
 
-    f32x4 bias1[4], bias2[4], bias3;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bias1[t][r] = a.net.b1[16 * t + 4 * q + r];
-            bias2[t][r] = a.net.b2[16 * t + 4 * q + r];
-        }
+    f32x4 bias3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
 
     // gradient accumulators (per wavefront, whole launch)
-    f32x4 gW1[4][KU], gW2[4][4], gW3[4], gb1[4], gb2[4], gb3, gls;
+    f32x4 gW1[4][KU], gW2[4][4], gW3[4], gb3, gls;
+    float gb1_l = 0.0f, gb2_l = 0.0f;                 // bias gradients of feature `lane` (layers 1 and 2)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         for (int u = 0; u < KU; ++u) gW1[t][u] = zero4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) gW2[t][u] = zero4;
-        gW3[t] = zero4; gb1[t] = zero4; gb2[t] = zero4;
+        gW3[t] = zero4;
     }
     gb3 = zero4; gls = zero4;
     float loss_sum = 0.0f, aux_sum = 0.0f, cnt_sum = 0.0f;
@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         }
         // ---- forward (recompute) -------------------------------------------------------------------
         f32x4 h1[4], h2[4], y;
+        int boff = 4 * q;                             // opaque to the optimiser: the bias reads stay inside the loop
+        asm volatile("" : "+v"(boff));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
+        for (int t = 0; t < 4; ++t) h1[t] = *reinterpret_cast<const f32x4*>(Bs + 16 * t + boff);
         if constexpr (STAGE) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
             if (tile + tile_stride < n_tiles) load_x(tile + tile_stride, xb);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
+        for (int t = 0; t < 4; ++t) h2[t] = *reinterpret_cast<const f32x4*>(Bs + HID + 16 * t + boff);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = 16 * (s >> 2) + 4 * q + (s & 3);
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { dz1[t] = zero4; gb2[t] += dz2[t]; }
+        for (int t = 0; t < 4; ++t) dz1[t] = zero4;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
             const int k = 16 * (s >> 2) + 4 * q + (s & 3);
@@ -398,13 +400,13 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
-            gb1[t] += dz1[t];
         }
 
         // ---- weight gradients: reduction over the 16 batch rows of the tile ---------------------------
         // transposed fragments: trX[t][s] = X[feature 16t + c][batch 4s + q]
         float tr_a[4][4], tr_b[4][4];
-        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4]) {
+        // rowsum: += sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
+        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4], float* rowsum) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -415,6 +417,12 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) out[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
+            if (rowsum) {
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) { p0 += scr[lane * TS + j]; p1 += scr[lane * TS + j + 1]; }
+                *rowsum += p0 + p1;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
@@ -428,14 +436,14 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         for (int s = 0; s < 4; ++s) tr_y[s] = scr[c * TS + 4 * s + q];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        transpose64(h2, tr_b);
+        transpose64(h2, tr_b, nullptr);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) gW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[t], 0, 0, 0);
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
-        transpose64(dz2, tr_a);
-        transpose64(h1, tr_b);
+        transpose64(dz2, tr_a, &gb2_l);
+        transpose64(h1, tr_b, nullptr);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
                 for (int t1 = 0; t1 < 4; ++t1)
                     gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
-        transpose64(dz1, tr_a);
+        transpose64(dz1, tr_a, &gb1_l);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
@@ -493,11 +501,6 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
     for (int m = 1; m < 16; m <<= 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                gb1[t][r] += __shfl_xor(gb1[t][r], m);
-                gb2[t][r] += __shfl_xor(gb2[t][r], m);
-            }
             gb3[r] += __shfl_xor(gb3[r], m);
             gls[r] += __shfl_xor(gls[r], m);
         }
@@ -508,14 +511,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
         aux_sum += __shfl_xor(aux_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
+    out[o_b1 + lane] = gb1_l;
+    out[o_b2 + lane] = gb2_l;
     if (c == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[o_b1 + 16 * t + 4 * q + r] = gb1[t][r];
-                out[o_b2 + 16 * t + 4 * q + r] = gb2[t][r];
-            }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < O) {
@@ -526,15 +524,35 @@ __global__ __launch_bounds__(256, 1) void mlp3_bwd_kernel(const BwdArgs a)
     if (lane == 0) { out[o_loss] = loss_sum; out[o_loss + 1] = aux_sum; out[o_loss + 2] = cnt_sum; }
 }
 
-// grads[p] = sum over slab rows, fixed order
+// grads[p] = sum over slab rows in a fixed order (bitwise reproducible): a workgroup owns 32 columns; its 8 row groups sum
+// rows rg, rg + 8, ... into four interleaved partial sums each, and thread column p adds the 8 group sums in order.
+// (One thread per column walking every row alone took 340 us for the critic's 13,249 columns x 1,024 rows.)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int64_t n_rows, int64_t stride,
                                                            int64_t n_cols, float* __restrict__ out)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_cols) return;
-    float s = 0.0f;
-    for (int64_t r = 0; r < n_rows; ++r) s += slab[r * stride + p];
-    out[p] = s;
+    __shared__ float part[8][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t p = (int64_t)blockIdx.x * 32 + col;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (p < n_cols) {
+        const float* base = slab + p;
+        int64_t r = rg;
+        for (; r + 24 < n_rows; r += 32) {
+            s0 += base[r * stride];
+            s1 += base[(r + 8) * stride];
+            s2 += base[(r + 16) * stride];
+            s3 += base[(r + 24) * stride];
+        }
+        for (; r < n_rows; r += 8) s0 += base[r * stride];
+    }
+    part[rg][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && p < n_cols) {
+        float s = part[0][col];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) s += part[g][col];
+        out[p] = s;
+    }
 }
 
 // clip_grad_norm_ over [0,n) followed by torch.optim.Adam's single-tensor update; one workgroup per parameter group
@@ -590,7 +608,7 @@ int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
     // staged input tiles (see mlp3_bwd_kernel): wide inputs whose 16-row tiles are contiguous, aligned spans
     const bool stage = ku > 4 && ba.ldx == ba.net.in_dim && (ba.net.in_dim & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(ba.x) & 15) == 0;
-    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 4 * HID * TS +
+    const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 2 * HID + 4 * HID * TS +
                                         (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
     const dim3 grid((unsigned)(n_waves / 4)), block(256);
 #define EM_BWD_ONE(KU_, STAGE_)                                                                                   \
@@ -661,7 +679,7 @@ int em_ppo_actor_grad(const em_mlp3* actor, const float* log_std, const float* e
     rc = launch_bwd<true>(ba, n_waves, s);
     if (rc) return rc;
     const int64_t np = ba.slab_stride - 3;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
     return em::hip_check(hipGetLastError(), "actor grad launch");
 }
@@ -687,7 +705,7 @@ int em_ppo_critic_grad(const em_mlp3* critic, const float* st_state, const int32
     rc = launch_bwd<false>(ba, n_waves, s);
     if (rc) return rc;
     const int64_t np = ba.slab_stride - 3;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
     return em::hip_check(hipGetLastError(), "critic grad launch");
 }

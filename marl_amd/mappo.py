@@ -324,7 +324,8 @@ class MAPPO:
         n_global = self.sync.sum_moments(self.moments)   # global advantage moments and transition count
         L = self._L
         na, nc = self.n_actor, self.n_critic
-        wa, wc = self._waves(E), self._waves(S)
+        # the 14-wide actor kernel is built for two workgroups per CU (mlp3_bwd_kernel, KU == 1)
+        wa, wc = self._waves(E, getattr(self, "actor_wg_per_cu", 2 if self.obs_dim <= 16 else 1)), self._waves(S)
         sa = int(L.em_ppo_slab_floats(self.obs_dim, self.action_dim, 1))
         sc = int(L.em_ppo_slab_floats(self.state_dim, 1, 0))
         if self._slab_a is None or self._slab_a.numel() < wa * sa:

@@ -16,11 +16,14 @@ def main():
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--actor-per-cu", type=int, default=0, help="workgroups per CU of the actor backward (0: library default)")
     a = ap.parse_args()
     cfg = dict(ENV_CONFIG)
     cfg["episode_length"] = a.horizon
     tr = MAPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=a.envs, verbose=False)
     tr.overlap_value = not a.no_overlap
+    if a.actor_per_cu:
+        tr.mappo.actor_wg_per_cu = a.actor_per_cu
     for it in range(a.iters + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
