@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             if (4 * q + r < O) { ls[r] = a.log_std[4 * q + r]; sd[r] = expf(ls[r]); }
     }
 
+    float ent_row = 0.0f;                              // entropy of the state-independent Gaussian, the same for every row
+    if constexpr (ACTOR) {
+        for (int o = 0; o < O; ++o) ent_row += 0.5f + 0.91893853320467274f + a.log_std[o];
+    }
     const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     const int64_t n_tiles = (a.n_rows + 15) >> 4;
     // x fragment of a tile: row c of the tile, features 16u + 4q + r
@@ -228,6 +232,16 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                                              (void __attribute__((address_space(3)))*)(dst + j * 256), 16, 0, 0);
         }
     };
+    // critic: a state's entry range {k, first} is fetched one tile ahead, so that its returns can be requested at the top of
+    // the tile; they are consumed after the forward pass, which hides both HBM round trips (they were exposed: the loss read
+    // ent_ret[first + j] right where it needed it, with a single wavefront per SIMD)
+    constexpr int KPRE = 4;
+    int n_k = 0;
+    int64_t n_first = 0;
+    if constexpr (!ACTOR) {
+        const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+        if (r0 < a.n_rows && q == 0) { n_k = a.st_k[r0]; n_first = a.st_first[r0]; }
+    }
     int cur = 0;
     if constexpr (STAGE) {
         const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         float p_act[4] = {0.f, 0.f, 0.f, 0.f}, p_adv = 0.0f, p_old = 0.0f;
         int p_k = 0;
         int64_t p_first = 0;
+        float p_ret[KPRE] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (ACTOR) {
             if (valid) {
 #pragma unroll
@@ -256,34 +271,89 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                 p_old = a.old_logp[row];
             }
         } else {
-            if (valid && q == 0) { p_k = a.st_k[row]; p_first = a.st_first[row]; }
+            p_k = n_k; p_first = n_first;
+            n_k = 0;
+            const int64_t rn = row + tile_stride * 16;
+            if (rn < a.n_rows && q == 0) { n_k = a.st_k[rn]; n_first = a.st_first[rn]; }
+#pragma unroll
+            for (int j = 0; j < KPRE; ++j) p_ret[j] = j < p_k ? a.ent_ret[p_first + j] : 0.0f;
         }
         // ---- forward (recompute) -------------------------------------------------------------------
         f32x4 h1[4], h2[4], y;
         int boff = 4 * q;                             // opaque to the optimiser: the bias reads stay inside the loop
         asm volatile("" : "+v"(boff));
+        // Weight fragments (A operands) come from LDS.  Every MFMA block below is software-pipelined by hand: the four
+        // fragments aw[t] (tile t, 4 consecutive reduction indices) of the NEXT batch - or of the next block's first
+        // batch - are requested in two halves, each right after the 8 MFMAs that consumed the registers it overwrites, i.e.
+        // 8 MFMAs (256 cycles) before its first use; the four accumulators of a batch stay independent.
+        // Left to itself the compiler reads a batch, waits for LDS, issues 16 MFMAs, and repeats: with one or two
+        // wavefronts per SIMD that wait was exposed about 20 times per tile.  (Per accumulator the order of the partial
+        // sums is unchanged, so the results are bitwise those of the plain loops.)
+#define EM_SB() __builtin_amdgcn_sched_barrier(0)
+        // one base register per access pattern; everything else is an immediate offset of the LDS instruction.  Row
+        // strides are even, so a lane's four consecutive weights are two 8-byte reads.
+        const float* rowW1 = W1s + c * S1 + boff;     // [feature row c][k = 4q ..]
+        const float* rowW2 = rowW1 + (HID * S1 + c * (S2 - S1));
+        const float* colW2 = W2s + boff * S2 + c;     // [k row 4q ..][feature column c]
+        // half fragments: reduction indices r = 2h, 2h + 1 of tile t (h = 0, 1)
+        auto ldRow = [&](const float* p, int h, f32x4& a) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * h);
+            a[2 * h] = v.x; a[2 * h + 1] = v.y;
+        };
+        auto ldCol = [&](const float* p, int h, f32x4& a) { a[2 * h] = p[2 * h * S2]; a[2 * h + 1] = p[(2 * h + 1) * S2]; };
+        auto ldW1 = [&](int u, int t, int h, f32x4& a) { ldRow(rowW1 + 16 * t * S1 + 16 * u, h, a); };
+        auto ldW2 = [&](int u, int t, int h, f32x4& a) { ldRow(rowW2 + 16 * t * S2 + 16 * u, h, a); };
+        auto ldW3 = [&](int u, int h, f32x4& a) { ldRow(rowW2 + HID * S2 + 16 * u, h, a); };
+        auto ldW3T = [&](int t, int h, f32x4& a) { ldCol(colW2 + HID * S2 + 16 * t, h, a); };
+        auto ldW2T = [&](int u, int t, int h, f32x4& a) { ldCol(colW2 + 16 * u * S2 + 16 * t, h, a); };
+        f32x4 aw[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h1[t] = *reinterpret_cast<const f32x4*>(Bs + 16 * t + boff);
+        for (int t = 0; t < 4; ++t) {
+            ldW1(0, t, 0, aw[t]); ldW1(0, t, 1, aw[t]);
+            h1[t] = *reinterpret_cast<const f32x4*>(Bs + 16 * t + boff);
+        }
         if constexpr (STAGE) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
+            auto ldX = [&](int u) {
                 const int k0 = 16 * u + 4 * q;
                 float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k0 < K1) xv = *reinterpret_cast<const float4*>(xt + c * K1 + k0);      // K1 % 4 == 0: whole or nothing
-                const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+                return f32x4{xv.x, xv.y, xv.z, xv.w};
+            };
+            f32x4 xcur = ldX(0), xnext = xcur;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int u = 0; u < KU; ++u) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k0 + r], xa[r], h1[t], 0, 0, 0);
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 2 * h; r < 2 * h + 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], xcur[r], h1[t], 0, 0, 0);
+                    EM_SB();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (u + 1 < KU) ldW1(u + 1, t, h, aw[t]); else ldW2(0, t, h, aw[t]);
+                    }
+                    if (h == 0 && u + 1 < KU) xnext = ldX(u + 1);
+                    EM_SB();
+                }
+                xcur = xnext;
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < KU * 4; ++s) {
-                const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+            for (int u = 0; u < KU; ++u) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h1[t], 0, 0, 0);
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 2 * h; r < 2 * h + 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], xb[u * 4 + r], h1[t], 0, 0, 0);
+                    EM_SB();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (u + 1 < KU) ldW1(u + 1, t, h, aw[t]); else ldW2(0, t, h, aw[t]);
+                    }
+                    EM_SB();
+                }
             }
         }
 #pragma unroll
@@ -298,11 +368,20 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = *reinterpret_cast<const f32x4*>(Bs + HID + 16 * t + boff);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2s[(16 * t + c) * S2 + k], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 2 * h; r < 2 * h + 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], h1[u][r], h2[t], 0, 0, 0);
+                EM_SB();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {      // last batch: layer 3's fragments, aw[t] = its batch t
+                    if (u < 3) ldW2(u + 1, t, h, aw[t]); else ldW3(t, h, aw[t]);
+                }
+                EM_SB();
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -310,9 +389,20 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
         y = bias3;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
-            y = __builtin_amdgcn_mfma_f32_16x16x4f32(W3s[c * S2 + k], h2[s >> 2][s & 3], y, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][r], h2[u][r], y, 0, 0, 0);
+            EM_SB();
+            ldW3T(u, 0, aw[u]); ldW3T(u, 1, aw[u]);   // the backward pass's first fragments, in flight during the loss
+            if constexpr (!ACTOR) {
+                // normalised returns of the state's first KPRE entries (mappo_algorithm.py:312-313), under the shadow of
+                // this dependent MFMA chain instead of after it
+                if (u == 0) {
+#pragma unroll
+                    for (int j = 0; j < KPRE; ++j) p_ret[j] = (p_ret[j] - a.norm_mean) / a.norm_scale;
+                }
+            }
+            EM_SB();
         }
 
         // ---- loss and dL/dy in accumulator layout: dy[r] = d/d out[row c][o = 4q + r] --------------
@@ -352,21 +442,26 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     gls[r] += g_lp * (d[r] * d[r] * iv - 1.0f) - a.ecoef * a.inv_L;   // d logp / d log_std ; entropy bonus
                 }
             }
-            if (valid && q == 0) {
-                float ent = 0.0f;
-                for (int o = 0; o < O; ++o) ent += 0.5f + 0.91893853320467274f + a.log_std[o];
-                aux_sum += ent;
-            }
+            if (valid && q == 0) aux_sum += ent_row;
         } else {
             if (valid && q == 0) {
                 const float v = y[0];
                 const int k = p_k;
                 const int64_t first = p_first;
                 float gsum = 0.0f;
-                for (int j = 0; j < k; ++j) {
-                    const float e = (v - a.norm_mean) / a.norm_scale - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
+                const float vn = (v - a.norm_mean) / a.norm_scale;
+#pragma unroll
+                for (int j = 0; j < KPRE; ++j) {
+                    if (j < k) {
+                        const float e = vn - p_ret[j];
+                        gsum += e;
+                        loss_sum += e * e;                                  // :314 before the 0.5 and the mean
+                    }
+                }
+                for (int j = KPRE; j < k; ++j) {
+                    const float e = vn - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
                     gsum += e;
-                    loss_sum += e * e;                                      // :314 before the 0.5 and the mean
+                    loss_sum += e * e;
                 }
                 cnt_sum += (float)k;
                 dy[0] = a.vcoef * a.inv_L * gsum / a.norm_scale;            // d(vcoef * 0.5 * mean(e^2)) / dv
@@ -379,10 +474,16 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) dz2[t] = zero4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 4q + r
+        for (int h = 0; h < 2; ++h) {      // dH2^T = W3^T . dY^T, reduction over o = 4q + r
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W3s[(4 * q + r) * S2 + 16 * t + c], dy[r], dz2[t], 0, 0, 0);
+            for (int r = 2 * h; r < 2 * h + 2; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], dy[r], dz2[t], 0, 0, 0);
+            EM_SB();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ldW2T(0, t, h, aw[t]);
+            EM_SB();
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -390,12 +491,22 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) dz1[t] = zero4;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+        for (int u = 0; u < 4; ++u) {      // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2s[k * S2 + 16 * t + c], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 2 * h; r < 2 * h + 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], dz2[u][r], dz1[t], 0, 0, 0);
+                EM_SB();
+                if (u < 3) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ldW2T(u + 1, t, h, aw[t]);
+                }
+                EM_SB();
+            }
         }
+#undef EM_SB
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
