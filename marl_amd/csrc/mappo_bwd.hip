@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     constexpr int NI = (4 * K1P + 63) / 64;           // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
     constexpr int XBUF = NI * 256;                    // floats per staged tile, whole copies (the tail of the last is slack)
     float* xs = Bs + 2 * HID + 4 * (HID * TS) + wave * (2 * XBUF);
+    // narrow inputs (register fragments, no staged copy): the tile's inputs transposed, [feature][row], for the dW1 product.
+    // (Reading X[b][i] back from global memory in that product put an L2/HBM round trip in front of its MFMAs.)
+    float* xtr = Bs + 2 * HID + 4 * (HID * TS) + wave * (K1P * TS);
 
     for (int i = threadIdx.x; i < HID * K1P; i += 256) {
         const int r = i / K1P, k = i - r * K1P;
@@ -220,16 +223,22 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     }
     // STAGE: asynchronous copy of a tile into one half of this wavefront's double buffer.  Lanes past the tile's last
     // valid float4 re-read its first one (always valid) into slack or into rows that every consumer masks.
+    // The copy is issued as inline assembly on purpose: told about an LDS-DMA (the builtin), the compiler cannot tell the two
+    // halves of the double buffer apart and puts s_waitcnt vmcnt(0) in front of the next LDS read of ANY kind - the
+    // "asynchronous" copy then cost a full HBM round trip at the top of every tile (3.7 k of a tile's 27 k cycles by
+    // in-kernel cycle stamps).  Here the kernel waits for it itself, at the end of the tile (s_waitcnt(0) below).  M0 = LDS
+    // byte address of the 1 KB slice (wave-uniform), lane l lands at M0 + 16 l.
     auto stage = [&](int64_t tile_, float* dst) {
         const float* gt = a.x + tile_ * 16 * (int64_t)K1;
         const int64_t rows_left = a.n_rows - tile_ * 16;
         const int nvv = (int)(rows_left < 16 ? rows_left : 16) * (K1 >> 2);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(dst);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int idx = lane + 64 * j;
             const float* src = gt + 4 * (idx < nvv ? idx : 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(dst + j * 256), 16, 0, 0);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 1024u * (unsigned)j);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory", "m0");
         }
     };
     // critic: a state's entry range {k, first} is fetched one tile ahead, so that its returns can be requested at the top of
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     // ent_ret[first + j] right where it needed it, with a single wavefront per SIMD)
     constexpr int KPRE = 4;
     int n_k = 0;
-    int64_t n_first = 0;
+    int n_first = 0;                                      // 32-bit on purpose: widening it here would wait for the load at once
     if constexpr (!ACTOR) {
         const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
         if (r0 < a.n_rows && q == 0) { n_k = a.st_k[r0]; n_first = a.st_first[r0]; }
@@ -363,6 +372,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         // the x fragment is dead from here on: fetch the next tile's into the same registers (the rest of this
         // iteration hides the HBM latency; one wavefront per SIMD has nobody else to hide it)
         if constexpr (PREFETCH) {
+#pragma unroll
+            for (int sx = 0; sx < KU * 4; ++sx) xtr[(16 * (sx >> 2) + 4 * q + (sx & 3)) * TS + c] = xb[sx];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (tile + tile_stride < n_tiles) load_x(tile + tile_stride, xb);
         }
 #pragma unroll
@@ -571,7 +583,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int i = 16 * u + c;
-                const float xv = (rb < a.n_rows && i < K1) ? xrow[i] : 0.0f;
+                float xv;
+                if constexpr (PREFETCH) xv = xtr[i * TS + 4 * s + q];      // zero where row >= n_rows or i >= K1 (load_x)
+                else xv = (rb < a.n_rows && i < K1) ? xrow[i] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
@@ -720,7 +734,8 @@ int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
     const bool stage = ku > 4 && ba.ldx == ba.net.in_dim && (ba.net.in_dim & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(ba.x) & 15) == 0;
     const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 2 * HID + 4 * HID * TS +
-                                        (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
+                                        (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0) +
+                                        (ku <= 4 ? 4 * (size_t)ku * 16 * TS : 0));
     const dim3 grid((unsigned)(n_waves / 4)), block(256);
 #define EM_BWD_ONE(KU_, STAGE_)                                                                                   \
     {                                                                                                             \
