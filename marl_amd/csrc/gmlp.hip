@@ -123,9 +123,12 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
 }
 
 // forward of one 16-row tile; xb = x fragment (row c, features 16u + 4q + r)
-template <int KU, int OT>
+struct NoHook { __device__ void operator()() const {} };
+// after_l1 runs once the first layer's products are issued (the x fragment is dead from there: a caller can start loads
+// that the epilogue needs into the registers it frees)
+template <int KU, int OT, class Hook = NoHook>
 __device__ inline void forward_tile(const float* lds, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
-                                    f32x4 (&y)[OT])
+                                    f32x4 (&y)[OT], Hook after_l1 = Hook())
 {
     using L = Lds<KU, OT>;
 #pragma unroll
@@ -139,6 +142,7 @@ __device__ inline void forward_tile(const float* lds, const float (&xb)[KU * 4],
         for (int t = 0; t < 4; ++t)
             h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W1 + (16 * t + c) * L::S1 + k], xb[s], h1[t], 0, 0, 0);
     }
+    after_l1();
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -359,38 +363,51 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 
     // STAGE: asynchronous copy of a tile, [16][K1] packed.  Lanes past the tile's last valid float4 re-read its first row
     // (always valid) into slack or into rows that every consumer masks.
-    auto stage = [&](int64_t tile_, float* dst) {
-        const int rv = K1 >> 2;
-        const int64_t p0 = r0 + tile_ * 16, rows_left = n_rows - tile_ * 16;
-        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * rv;
+    // The copy is inline assembly on purpose (see mlp3_bwd_kernel in mappo_bwd.hip): behind the LDS-DMA builtin the compiler
+    // waits vmcnt(0) before the next LDS read of any kind; the kernel waits for the copy itself at the end of the tile.
+    // grow_t = global row of tile row c (through the permutation), fetched one tile ahead by the caller; lanes 0..15 serve
+    // the shuffles, so no index load sits in front of the copy.
+    const uint32_t rv = (uint32_t)K1 >> 2, rv_magic = (uint32_t)((0x100000000ull + rv - 1u) / rv);
+    auto stage = [&](int64_t tile_, int64_t grow_t, float* dst) {
+        const int64_t rows_left = n_rows - tile_ * 16;
+        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * (int)rv;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(dst);
+        const int g_lo = (int)(uint32_t)grow_t, g_hi = (int)(uint32_t)((uint64_t)grow_t >> 32);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int idx = lane + 64 * j;
-            const bool ok = idx < nvv;
-            const int rw = ok ? idx / rv : 0, v = ok ? idx - rw * rv : 0;
-            const int64_t gr = a.perm ? (int64_t)a.perm[p0 + rw] : p0 + rw;
+            int idx = lane + 64 * j;
+            idx = idx < nvv ? idx : 0;
+            const uint32_t rw = __umulhi((uint32_t)idx, rv_magic), v = (uint32_t)idx - rw * rv;
+            const int64_t gr = (int64_t)(((uint64_t)(uint32_t)__shfl(g_hi, (int)rw) << 32) | (uint32_t)__shfl(g_lo, (int)rw));
             const float* src = a.x + gr * a.ldx + 4 * v;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(dst + j * 256), 16, 0, 0);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 1024u * (unsigned)j);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory", "m0");
         }
     };
+    auto global_row = [&](int64_t tile_) -> int64_t {    // global row of (tile_, c)
+        const int64_t r_ = tile_ * 16 + c;
+        if (tile_ >= n_tiles || r_ >= n_rows) return 0;     // never dereferenced
+        return a.perm ? (int64_t)a.perm[r0 + r_] : r0 + r_;
+    };
     int cur = 0;
+    const int64_t tile_stride = (int64_t)a.split * 4;
+    int64_t grow_cur = global_row((int64_t)part * 4 + wave), grow_next = global_row((int64_t)part * 4 + wave + tile_stride);
     if constexpr (STAGE) {
         const int64_t t0 = (int64_t)part * 4 + wave;
-        if (t0 < n_tiles) stage(t0, xs);
+        if (t0 < n_tiles) stage(t0, grow_cur, xs);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    const int64_t tile_stride = (int64_t)a.split * 4;
     for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;
         const bool valid = row < n_rows;
-        const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
+        const int64_t grow = valid ? grow_cur : 0;
+        const int64_t grow_nn = global_row(tile + 2 * tile_stride);       // needed at the top of the next tile
         const float* xt = xs + cur * XBUF;
         float xb[KU * 4];
         if constexpr (STAGE) {
-            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF);
+            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, grow_next, xs + (cur ^ 1) * XBUF);
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int k0 = 16 * u + 4 * q;
@@ -407,7 +424,21 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
             else p_ret = a.ret[grow];
         }
         f32x4 h1[4], h2[4], y[OT], dy[OT];
-        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y);
+        // actor: the row's recorded action, requested once the first layer is issued (into the registers the x fragment
+        // frees) and consumed by the loss two layers later; read in place, the loss waited a full memory round trip for it
+        float p_act[OT][4];
+        auto fetch_actions = [&]() {
+            if constexpr (ACTOR) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * ot + 4 * q + r;
+                        p_act[ot][r] = (o < O && valid) ? a.action[grow * O + o] : 0.0f;
+                    }
+            }
+        };
+        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y, fetch_actions);
 
         // ---- loss and dL/dy in accumulator layout: dy[ot][r] = d/d out[row c][o = 16 ot + 4q + r] ------------
         if constexpr (ACTOR) {
@@ -420,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     float d = 0.0f;
                     if (o < O && valid) {
                         const float ls = lds[L::LS + o];
-                        d = a.action[grow * O + o] - y[ot][r];
+                        d = p_act[ot][r] - y[ot][r];
                         lp += -(d * d) / den_t[o] - ls - HALF_LOG_2PI;
                     }
                     dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
@@ -578,6 +609,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
             __builtin_amdgcn_wave_barrier();
             cur ^= 1;
         }
+        grow_cur = grow_next;
+        grow_next = grow_nn;
     }
 
     // ---- this wavefront's slab row: [w1 | b1 | w2 | b2 | w3 | b3 | (log_std) | loss, aux, count] ---------------
