@@ -89,6 +89,39 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
     const int64_t n_tiles = (n_rows + 15) >> 4;
     if ((int64_t)blockIdx.x * 4 >= n_tiles) return;    // whole workgroup idle (uniform: safe before the barrier)
 
+    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+
+    // x fragment of a tile: row c of the tile, features 16u + 4q + r
+    auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
+        const int64_t row_ = tile_ * 16 + c;
+        const bool valid_ = row_ < n_rows;
+        const float* xr = a.x + (row_base + (valid_ ? row_ : 0)) * a.ldx;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = 16 * u + 4 * q;
+            if (vec_ok && k + 3 < K1) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                xb_[u * 4 + 0] = v.x; xb_[u * 4 + 1] = v.y; xb_[u * 4 + 2] = v.z; xb_[u * 4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xb_[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
+            }
+        }
+        if (!valid_) {
+#pragma unroll
+            for (int s = 0; s < KU * 4; ++s) xb_[s] = 0.0f;
+        }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    float xb[KU * 4];
+    // The first tile's inputs (and, for the policy epilogue, its entries' environment and agent) are requested before the
+    // weights are staged: their memory round trip then runs beside the staging instead of in front of the first MFMA.
+    load_x((int64_t)blockIdx.x * 4 + wave, xb);
+    int n_env = 0, n_agent = 0;
+    if constexpr (MODE == 1) {
+        const int64_t r_ = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+        if (r_ < n_rows) { n_env = a.ent_env[row_base + r_]; n_agent = (int)a.ent_agent[row_base + r_]; }
+    }
     // ---- weights: HBM/L2 -> LDS once per workgroup (coalesced), LDS -> register fragments once per wavefront
     extern __shared__ __align__(16) float lds[];
     constexpr int K1P = KU * 16;
@@ -151,32 +184,6 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
 
-    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
-
-    // x fragment of a tile: row c of the tile, features 16u + 4q + r
-    auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
-        const int64_t row_ = tile_ * 16 + c;
-        const bool valid_ = row_ < n_rows;
-        const float* xr = a.x + (row_base + (valid_ ? row_ : 0)) * a.ldx;
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int k = 16 * u + 4 * q;
-            if (vec_ok && k + 3 < K1) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + k);
-                xb_[u * 4 + 0] = v.x; xb_[u * 4 + 1] = v.y; xb_[u * 4 + 2] = v.z; xb_[u * 4 + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xb_[u * 4 + r] = (k + r) < K1 ? xr[k + r] : 0.0f;
-            }
-        }
-        if (!valid_) {
-#pragma unroll
-            for (int s = 0; s < KU * 4; ++s) xb_[s] = 0.0f;
-        }
-    };
-    const int64_t tile_stride = (int64_t)gridDim.x * 4;
-    float xb[KU * 4];
-    load_x((int64_t)blockIdx.x * 4 + wave, xb);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;          // row relative to row_base
         const bool valid = row < n_rows;
@@ -192,7 +199,16 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
         // the x fragment is dead from here on: fetch the next tile's while this one finishes (one wavefront per SIMD)
-        if (tile + tile_stride < n_tiles) load_x(tile + tile_stride, xb);
+        int c_env = 0, c_agent = 0;
+        if constexpr (MODE == 1) { c_env = n_env; c_agent = n_agent; }
+        if (tile + tile_stride < n_tiles) {
+            load_x(tile + tile_stride, xb);
+            if constexpr (MODE == 1) {
+                const int64_t r_ = (tile + tile_stride) * 16 + c;
+                n_env = 0; n_agent = 0;
+                if (r_ < n_rows) { n_env = a.ent_env[row_base + r_]; n_agent = (int)a.ent_agent[row_base + r_]; }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
 #pragma unroll
@@ -225,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         } else {
             // ---- policy epilogue ---------------------------------------------------------------------
             const int n = a.n_nodes;
-            const int env = valid ? a.ent_env[grow] : 0;
-            const int agent = valid ? (int)a.ent_agent[grow] : 0;
+            const int env = valid ? c_env : 0;
+            const int agent = valid ? c_agent : 0;
             float act[4];
             float lp = 0.0f;
             float best = -__builtin_inff();
