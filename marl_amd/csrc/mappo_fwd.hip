@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #define EM_SCAN_CHUNK 256
 #endif
 #ifndef EM_SCAN_UNROLL
-#define EM_SCAN_UNROLL 4
+#define EM_SCAN_UNROLL 8
 #endif
 constexpr int CHUNK = EM_SCAN_CHUNK;    // environments per workgroup of the two kernels
 
@@ -357,6 +357,17 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     __shared__ int8_t s_rank[CHUNK * 64];       // arrival ranks of the chunk (n <= 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
+    // the chunk's arrival ranks depend on nothing: requested first (held in registers until the LDS tile is free to take
+    // them), so their round trip runs beside the scan instead of after it
+    const int64_t cb0 = (int64_t)blockIdx.x * CHUNK;
+    int8_t rk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rk[j] = (int8_t)-1;
+    if (n <= 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < n) { const int64_t i_ = cb0 * n + (int64_t)j * CHUNK + tid; rk[j] = i_ < B * n ? rank[i_] : (int8_t)-1; }
+    }
 
     // ---- totals of the preceding chunks and of the whole step ----------------------------------------
     unsigned long long pre = 0, all = 0;
@@ -420,7 +431,13 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     const int n_loc = (int)(ctot >> 32);
     const int w = n + 4, sw = n * w;
     const int64_t cb = (int64_t)blockIdx.x * CHUNK;
-    for (int i = tid; i < CHUNK * n; i += CHUNK) s_rank[i] = (cb * n + i) < B * n ? rank[cb * n + i] : (int8_t)-1;
+    if (n <= 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < n) s_rank[j * CHUNK + tid] = rk[j];
+    } else {
+        for (int i = tid; i < CHUNK * n; i += CHUNK) s_rank[i] = (cb * n + i) < B * n ? rank[cb * n + i] : (int8_t)-1;
+    }
     __syncthreads();
     const uint32_t magic_w = (uint32_t)((0x100000000ull + (uint32_t)w - 1u) / (uint32_t)w);   // e / w for e < 2^16
     if ((sw & 3) == 0) {   // rows are 16-byte multiples (obs and st_state bases are 16-byte aligned by contract)
