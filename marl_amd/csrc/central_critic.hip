@@ -132,15 +132,25 @@ __device__ inline void gather_h1(const CCArgs& a, const float* lds, int k, int64
     int kmax = k;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(kmax, m); kmax = o > kmax ? o : kmax; }
-    for (int j = 0; j < kmax; ++j) {
+    // One entry ahead: the loads of entry j + 1 are in flight while entry j is added, so the state's k partial rows cost
+    // one memory round trip in all instead of one each (the sum keeps its order: entry 0, 1, ...).
+    float4 v[4], vn[4];
+    auto fetch = [&](int j, float4 (&dst)[4]) {
         if (j < k) {
             const float4* src = reinterpret_cast<const float4*>(a.P + (first + j) * HID);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 v = src[4 * t + q];
-                h1[t][0] += v.x; h1[t][1] += v.y; h1[t][2] += v.z; h1[t][3] += v.w;
-            }
+            for (int t = 0; t < 4; ++t) dst[t] = src[4 * t + q];
         }
+    };
+    fetch(0, v);
+    for (int j = 0; j < kmax; ++j) {
+        fetch(j + 1, vn);
+        if (j < k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { h1[t][0] += v[t].x; h1[t][1] += v[t].y; h1[t][2] += v[t].z; h1[t][3] += v[t].w; }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = vn[t];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
