@@ -122,12 +122,15 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
         tr.train_episode(explore=True, record_buffer=True)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        entries, _ = tr.mappo.buffer.totals()
+        entries, states = tr.mappo.buffer.totals()
         tr.mappo.update()
         torch.cuda.synchronize(device)
+        flops[0] += 3.0 * tr.mappo.num_sgd_iter * (11392.0 * entries + 26240.0 * states)   # fwd + 2x bwd per epoch
         return entries, t1 - t0, time.perf_counter() - t1
 
+    flops = [0.0]
     iteration()                                   # warmup: allocator, code objects, RCCL channels
+    flops[0] = 0.0
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -159,6 +162,11 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
             "agent_steps_per_s": world * n_envs * T * tr.n_agents * iters / elapsed, "n_envs_per_gpu": n_envs,
             "iterations": iters, "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters,
             "update_s_rank0": upd / iters, "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
+            # the update is the GEMM-shaped part: algorithmic FLOPs of rank 0's actor/critic forward + backward over its
+            # wall time (GAE, reductions and Adam included) against the dense f32 matrix-core peak
+            "update_roofline": {"bound": "mfma", "achieved": flops[0] / max(upd, 1e-9) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                "frac": flops[0] / max(upd, 1e-9) / 1e12 / 157.3,
+                                "note": "actor 14-64-64-11 over the transitions, critic 140-64-64-1 once per (env, step)"},
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 
