@@ -162,14 +162,18 @@ __device__ inline void forward_tile(const float* lds, const float (&xb)[KU * 4],
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
+    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[ot][r] = lds[L::B3 + 16 * ot + 4 * q + r];
+    // reduction index outside, output tile inside: the OT accumulators are independent, so consecutive MFMAs do not wait
+    // for each other (tile by tile, each product waited for the previous one on the same accumulator); the order of the
+    // partial sums of an accumulator is unchanged
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+    for (int s = 0; s < 16; ++s) {
+        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
             y[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + c) * S2 + k], h2[s >> 2][s & 3], y[ot], 0, 0, 0);
-        }
     }
     // y[ot][r] = out[row c][o = 16 ot + 4q + r]
 }
@@ -444,18 +448,22 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         if constexpr (ACTOR) {
             float lp = 0.0f;
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
+            for (int ot = 0; ot < OT; ++ot) {
+                // the lane's four table entries of this output tile in one 16-byte read each, outside the per-element
+                // branches (read inside them, every element waited for its own two LDS round trips)
+                const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lds + L::LS + 16 * ot + 4 * q);
+                const f32x4 den4 = *reinterpret_cast<const f32x4*>(den_t + 16 * ot + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * ot + 4 * q + r;
                     float d = 0.0f;
                     if (o < O && valid) {
-                        const float ls = lds[L::LS + o];
                         d = p_act[ot][r] - y[ot][r];
-                        lp += -(d * d) / den_t[o] - ls - HALF_LOG_2PI;
+                        lp += -(d * d) / den4[r] - ls4[r] - HALF_LOG_2PI;
                     }
                     dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
                 }
+            }
             lp += __shfl_xor(lp, 16);
             lp += __shfl_xor(lp, 32);
             float g_lp = 0.0f;
@@ -472,19 +480,21 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 if (q == 0) { loss_sum += fminf(su1, su2); cnt_sum += 1.0f; aux_sum += ent_row; }
             }
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
+            for (int ot = 0; ot < OT; ++ot) {
+                const f32x4 iv4 = *reinterpret_cast<const f32x4*>(iv_t + 16 * ot + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * ot + 4 * q + r;
                     const float d = dy[ot][r];
                     float out = 0.0f;
                     if (o < O && valid) {
-                        const float iv = iv_t[o];
+                        const float iv = iv4[r];
                         out = g_lp * d * iv;                                // d logp / d mu
                         gls[ot][r] += g_lp * (d * d * iv - 1.0f) - a.ecoef * inv_L;   // d logp / d log_std ; entropy bonus
                     }
                     dy[ot][r] = out;
                 }
+            }
         } else {
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) dy[ot] = zero4;
