@@ -106,12 +106,49 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
     const float* w1 = net.w1 + go;
     const float* w2 = net.w2 + go;
     const float* w3 = net.w3 + go;
-    for (int i = threadIdx.x; i < HID * L::K1P; i += 256) {
-        const int r = i / L::K1P, k = i - r * L::K1P;
-        lds[L::W1 + r * L::S1 + k] = k < K1 ? w1[r * K1 + k] : 0.0f;
+    // fixed trip counts, read in batches of 8 before anything is written: as plain loops every iteration waited for its own
+    // load (56 L2 round trips in a row, 28 k cycles by in-kernel stamps - half of a rollout launch of the policy kernel)
+    constexpr int N1 = HID * L::K1P / 256, N2 = HID * HID / 256, N3 = 16 * OT * HID / 256, BATCH = 8;
+    static_assert(HID * L::K1P % 256 == 0 && 16 * OT * HID % 256 == 0, "whole passes of the workgroup");
+#pragma unroll
+    for (int j0 = 0; j0 < N1; j0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = (j0 + j) * 256 + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
+            v[j] = (j0 + j < N1 && k < K1) ? w1[r * K1 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = (j0 + j) * 256 + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
+            if (j0 + j < N1) lds[L::W1 + r * L::S1 + k] = v[j];
+        }
     }
-    for (int i = threadIdx.x; i < HID * HID; i += 256) lds[L::W2 + (i >> 6) * S2 + (i & 63)] = w2[i];
-    for (int i = threadIdx.x; i < 16 * OT * HID; i += 256) lds[L::W3 + (i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? w3[i] : 0.0f;
+#pragma unroll
+    for (int j0 = 0; j0 < N2; j0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) v[j] = (j0 + j < N2) ? w2[(j0 + j) * 256 + threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = (j0 + j) * 256 + threadIdx.x;
+            if (j0 + j < N2) lds[L::W2 + (i >> 6) * S2 + (i & 63)] = v[j];
+        }
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < N3; j0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = (j0 + j) * 256 + threadIdx.x;
+            v[j] = (j0 + j < N3 && (i >> 6) < O) ? w3[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = (j0 + j) * 256 + threadIdx.x;
+            if (j0 + j < N3) lds[L::W3 + (i >> 6) * S2 + (i & 63)] = v[j];
+        }
+    }
     if (threadIdx.x < HID) {
         lds[L::B1 + threadIdx.x] = net.b1[go + threadIdx.x];
         lds[L::B2 + threadIdx.x] = net.b2[go + threadIdx.x];
