@@ -252,6 +252,13 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
     if ((int64_t)part * 4 >= n_tiles) return;          // uniform over the workgroup: safe before the barrier
     stage_weights<KU, OT>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g);
     __syncthreads();
+    // sigma = exp(log_std) of every output, once per workgroup (the same expression, so the same bits as evaluating it per
+    // element and tile in the epilogue, where it cost 4 x OT exp() per row)
+    float* sd_t = lds + L::END;
+    if constexpr (MODE == MODE_POLICY) {
+        if (threadIdx.x < 16 * OT) sd_t[threadIdx.x] = expf(lds[L::LS + threadIdx.x]);
+        __syncthreads();
+    }
 
     for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
         const int64_t row = tile * 16 + c;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
                     float v = y[ot][r];
                     if (a.explore && on) {
                         const float ls = lds[L::LS + o];
-                        const float sd = expf(ls);
+                        const float sd = sd_t[o];
                         const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
                         v = y[ot][r] + e * sd;                                  // rsample, mappo_algorithm.py:65
                         const float d = v - y[ot][r];
@@ -834,7 +841,8 @@ int check_gnet(const em_gmlp* net)
 size_t lds_bytes(int ku, int ot, bool bwd, bool stage = false)
 {
     const int s1 = (ku * 16 + 2) | 2;
-    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 0) +
+    // forward: + sd table of the policy epilogue (16 ot); backward: + transpose scratch and the two loss tables
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 16 * ot) +
                             (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
 }
 
