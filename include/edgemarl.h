@@ -329,6 +329,17 @@ int em_value_step(const em_rollout *ro, int32_t t, const em_mlp3 *critic, float 
 int em_gae(const em_rollout *ro, double gamma, double lam, double *partials, int64_t partials_capacity,
            double *moments3, void *stream);
 
+/* em_gae for callers that cannot allocate or carry a workspace (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: same arithmetic and outputs as em_gae
+ * (mappo_algorithm.py:241-262,293), but the per-workgroup moment partials live in a fixed array inside the library
+ * (96 KB per GPU, held until the process ends) instead of a caller-owned buffer.  The call allocates nothing (no
+ * hipMalloc/hipFree, no allocating library routine); its first call on a device resolves the array's device address
+ * (hipGetSymbolAddress), so make one call per device before a graph capture begins.  n_envs above
+ * EM_GAE_STATIC_MAX_ENVS is rejected with EM_ERR_INVALID.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (two streams, two host threads) race; calls on one stream are ordered and need no clearing. */
+#define EM_GAE_STATIC_MAX_ENVS (1 << 20)
+int em_gae_static(const em_rollout *ro, double gamma, double lam, double *moments3, void *stream);
+
 /* Floats per slab row used by the two gradient kernels below: all parameters of the network in the
  * order [w1|b1|w2|b2|w3|b3|(log_std)] followed by 3 loss sums. */
 int64_t em_ppo_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor);

@@ -149,6 +149,8 @@ def lib() -> C.CDLL:
     L.em_value_step.restype = C.c_int
     f32, f64 = C.c_float, C.c_double
     L.em_gae.argtypes = [C.POINTER(EmRollout), f64, f64, vp, i64, vp, vp]
+    L.em_gae_static.argtypes = [C.POINTER(EmRollout), f64, f64, vp, vp]
+    L.em_gae_static.restype = C.c_int
     L.em_ppo_slab_floats.argtypes = [C.c_int32, C.c_int32, i32]
     L.em_ppo_slab_floats.restype = i64
     L.em_ppo_actor_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp, i64, vp, vp, vp]

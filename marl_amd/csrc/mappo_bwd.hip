@@ -9,6 +9,7 @@
 //   * reduce_slabs_kernel, adam_kernel: slab reduction, clip_grad_norm_ (:328-329) and Adam (:331-332)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
     }
     if (threadIdx.x < 3) moments[threadIdx.x] = red[threadIdx.x][0];
 }
+
+// Scratch of em_gae_static (the entry point that allocates nothing): the per-workgroup advantage moments that em_gae
+// takes as its caller-owned `partials` argument, 3 doubles per 256 environments, EM_GAE_STATIC_MAX_ENVS environments at
+// most = 96 KB that every GPU the library runs on holds until the process ends.  In host code this NAME is only a
+// stand-in for the symbol; the device address comes from hipGetSymbolAddress (once per device, kept in
+// g_gae_scratch_ptr) and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) double scratch[3 * (EM_GAE_STATIC_MAX_ENVS / 256)];
+constexpr int GAE_MAX_DEVICES = 64;
+static std::atomic<double*> g_gae_scratch_ptr[GAE_MAX_DEVICES];
 
 // ------------------------------------------------------------------------------------------------
 // fused forward-recompute + loss + backward
@@ -776,6 +786,32 @@ int em_gae(const em_rollout* ro, double gamma, double lam, double* partials, int
                        ro->value_tb, ro->done_tb, ro->k_tb, ro->first_tb, gamma, lam, ro->ent_adv, ro->ent_ret, partials);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partials, blocks, moments3);
     return em::hip_check(hipGetLastError(), "gae launch");
+}
+
+int em_gae_static(const em_rollout* ro, double gamma, double lam, double* moments3, void* stream)
+{
+    if (!ro || !moments3) return em::fail(EM_ERR_INVALID, "em_gae_static: null argument");
+    if (ro->n_envs < 1 || ro->n_envs > EM_GAE_STATIC_MAX_ENVS)
+        return em::fail(EM_ERR_INVALID, "em_gae_static: n_envs %lld is outside 1..%lld (the library's fixed scratch); use em_gae "
+                        "with a caller-owned partials buffer", (long long)ro->n_envs, (long long)EM_GAE_STATIC_MAX_ENVS);
+    int dev = -1;
+    EM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= GAE_MAX_DEVICES) return em::fail(EM_ERR_INVALID, "em_gae_static: device index %d out of range", dev);
+    double* part = g_gae_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!part) {
+        // once per device, with that device current: every GPU holds its own copy of the array at its own address
+        EM_HIP(hipGetSymbolAddress((void**)&part, HIP_SYMBOL(scratch)));
+        if (!part) return em::fail(EM_ERR_HIP, "em_gae_static: the scratch symbol has no device address");
+        g_gae_scratch_ptr[dev].store(part, std::memory_order_release);
+    }
+    const int64_t blocks = (ro->n_envs + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    // rows [0, blocks) of the scratch are written in full by gae_kernel before sum_partials_kernel reads exactly those
+    // rows, so whatever an earlier (larger) call left behind is never read and nothing has to be cleared
+    hipLaunchKernelGGL(gae_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ro->n_envs, ro->horizon, ro->reward_tb,
+                       ro->value_tb, ro->done_tb, ro->k_tb, ro->first_tb, gamma, lam, ro->ent_adv, ro->ent_ret, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, part, blocks, moments3);
+    return em::hip_check(hipGetLastError(), "gae (static scratch) launch");
 }
 
 int64_t em_ppo_slab_floats(int32_t in_dim, int32_t out_dim, int is_actor)
