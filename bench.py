@@ -21,6 +21,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -244,7 +245,7 @@ def _cpu_model() -> str:
 def time_env_steps(device, rank, world, B, steps, warmup):
     """Times `steps` launches of em_step over B environments per GPU (configs[1] protocol): warmup, barrier +
     synchronize, HIP events on the launch stream around the timed region, barrier + synchronize, MAX over ranks.
-    Returns (wall seconds, device milliseconds between the events, n_nodes, episode length, record bytes)."""
+    Returns (wall seconds, device milliseconds between the events, n_nodes, episode length, record bytes, kernel variant)."""
     import torch.distributed as dist
     from marl_amd.config import ENV_CONFIG
     from marl_amd.env import BatchedEdgeSimGym
@@ -298,9 +299,10 @@ def time_env_steps(device, rank, world, B, steps, warmup):
     # parity spot check outside the timed region: a finite reward
     assert bool(torch.isfinite(env.reward).all())
     record_bytes = env.record_bytes
+    variant = env.kernel_variant()
     env.close()
     del pool
-    return elapsed, dev_ms, n, T, record_bytes
+    return elapsed, dev_ms, n, T, record_bytes, variant
 
 
 def fused_leg(device, rank, world, B, k_steps=250, launches=8):
@@ -480,13 +482,55 @@ def guarded(name, fn, *a, **k):
         return {"error": repr(e)[:300]}
 
 
+def kernel_signature() -> str:
+    """Hash of the env-step kernel's sources: a PMC traffic figure is only echoed for the code it was measured on."""
+    import hashlib
+    hsh = hashlib.sha1()
+    for name in ("edge_env.hip", "em_env_math.h", "em_common.h"):
+        with open(os.path.join(ROOT, "marl_amd", "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
 def traffic_for(B):
-    """HBM bytes per launch measured with the PMC passes of tools/measure_traffic.sh (profiles/traffic.json)."""
+    """HBM bytes per em_step launch from the separate rocprofv3 --pmc passes of tools/measure_traffic.sh (counters cannot
+    be read from inside this process).  profiles/traffic.json records the kernel signature it was measured on; a figure
+    taken on other kernel code is omitted (null), never echoed.  Returns (bytes or None, provenance string or None)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(str(B))
+        doc = json.load(open(tpath))
+        if doc.get("kernel_signature") != kernel_signature():
+            return None, None
+        v = doc.get(str(B))
+        return (v, f"profiles/traffic.json ({doc.get('measured', 'tools/measure_traffic.sh')})") if v is not None else (None, None)
     except Exception:
-        return None
+        return None, None
+
+
+def launch_command(n_gpus: int, argv: list, port: int) -> list:
+    """Command line of the N-rank job that `python bench.py --gpus N` starts when it is not already a rank: the same
+    launcher the driver uses (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), the same argv."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(n_gpus: int, argv: list) -> int:
+    """Parent of an N-rank run.  It never touches the GPU (no HIP call, no torch.cuda query before this point): the
+    ranks are CHILD processes and the parent only waits for them and passes their exit code on."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's peer mappings need it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launch_command(n_gpus, argv, free_port())
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
 def main():
@@ -501,7 +545,11 @@ def main():
     ap.add_argument("--mappo-envs", type=int, default=65536, help="environments per GPU of the MAPPO measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s); running with {world}", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -520,80 +568,87 @@ def main():
     torch.cuda.set_device(device)
 
     B = args.envs
-    elapsed, dev_ms, n, T, record_bytes = time_env_steps(device, rank, world, B, args.steps, args.warmup)
-    wg_waves = 5 if B < 65536 else 8          # the library's automatic choice (em_set_workgroup_waves)
-    scale = None
+    elapsed, dev_ms, n, T, record_bytes, variant = time_env_steps(device, rank, world, B, args.steps, args.warmup)
+
+    # the headline line exists from here on; the legs below only add objects to it.  A watchdog prints what there is and
+    # ends the process if a secondary leg wedges (a collective that never returns cannot be caught as an exception), so a
+    # hang beside the headline costs the legs, not the line.
+    agent_steps = world * B * n * args.steps
+    bytes_launch = algorithmic_bytes_per_env_step(n, record_bytes) * B
+    launch_s = dev_ms * 1e-3 / args.steps          # HIP events on the launch stream, reset launches included
+    achieved = bytes_launch / launch_s / 1e9
+    traffic, traffic_src = traffic_for(B)
+    line = {
+        "metric": "agent-steps/sec (env step)",
+        "value": agent_steps / elapsed,
+        "unit": "agent-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"EdgeSimGym default topology, {B} batched envs/GPU, random actions, step-only kernel",
+                   "n_envs_per_gpu": B, "n_nodes": n, "episode_length": T, "rng": "philox4x32-10 in-kernel",
+                   "exploration": "disabled", "lanes_per_env": variant["lanes_per_env"],
+                   "workgroup": f"{variant['workgroup_waves'] - 1} worker + 1 scalar wavefronts",
+                   "parallelism": f"dp{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": variant["kernel"], "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src, "bytes_per_launch": bytes_launch, "avg_launch_us": launch_s * 1e6},
+    }
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return
+        if note:
+            line["legs_cut_short"] = note
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        emit(f"watchdog after {limit:.0f} s: a secondary leg did not return; objects present so far are complete")
+        time.sleep(2.0 if rank == 0 else 6.0)      # rank 0's line first, then everyone leaves
+        os._exit(0)
+
+    limit = float(os.environ.get("EDGEMARL_BENCH_WATCHDOG_S", "900"))
+    timer = threading.Timer(limit, watchdog)
+    timer.daemon = True
+    timer.start()
+
     if not args.no_scale_point and B != 65536:
         # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)
         k = max(200, args.steps // 4)
         res = guarded("scale_point", time_env_steps, device, rank, world, 65536, k, max(20, args.warmup // 4))
-        scale = (65536, k, res[0], res[1]) if isinstance(res, tuple) else None
-    fused = None
-    scaled = None
-    marl_env = None
-    if not args.no_scale_point:
-        fused = guarded("fused_steps", fused_leg, device, rank, world, B)
-        scaled = guarded("scaled_topology", scaled_leg, device, rank, world)
-        marl_env = guarded("pymarl_env", marl_env_leg, device, rank, world)
-    mappo = None
-    ippo = None
-    mappo_scaled = None
-    if not args.no_mappo:
-        mappo = guarded("mappo", mappo_leg, device, rank, world, args.mappo_envs)
-        ippo = guarded("ippo_scaled", ippo_leg, device, rank, world)
-        mappo_scaled = guarded("mappo_scaled", ippo_leg, device, rank, world, algorithm="mappo")
-
-    if rank == 0:
-        agent_steps = world * B * n * args.steps
-        bytes_launch = algorithmic_bytes_per_env_step(n, record_bytes) * B
-        launch_s = dev_ms * 1e-3 / args.steps          # HIP events on the launch stream, reset launches included
-        achieved = bytes_launch / launch_s / 1e9
-        traffic = traffic_for(B)
-        line = {
-            "metric": "agent-steps/sec (env step)",
-            "value": agent_steps / elapsed,
-            "unit": "agent-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "EdgeSimGym default topology, 4096 batched envs/GPU, random actions, step-only kernel",
-                       "n_envs_per_gpu": B, "n_nodes": n, "episode_length": T, "rng": "philox4x32-10 in-kernel",
-                       "exploration": "disabled", "lanes_per_env": 16,
-                       "workgroup": f"{wg_waves - 1} worker + 1 scalar wavefronts"},
-            "roofline": {"bound": "hbm", "kernel": "env_kernel<16,philox,step>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_launch, "avg_launch_us": launch_s * 1e6},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline)
-        if scale is not None:
-            sb, sk, se, sd = scale
-            s_bytes = algorithmic_bytes_per_env_step(n, record_bytes) * sb
-            s_ach = s_bytes / (sd * 1e-3 / sk) / 1e9
-            line["scale_point"] = {"n_envs_per_gpu": sb, "steps": sk, "value": world * sb * n * sk / se,
-                                   "unit": "agent-steps/s", "avg_launch_us": sd * 1e3 / sk,
+        if isinstance(res, tuple):
+            se, sd, sv = res[0], res[1], res[5]
+            s_bytes = algorithmic_bytes_per_env_step(n, record_bytes) * 65536
+            s_ach = s_bytes / (sd * 1e-3 / k) / 1e9
+            s_traffic, s_src = traffic_for(65536)
+            line["scale_point"] = {"n_envs_per_gpu": 65536, "steps": k, "value": world * 65536 * n * k / se,
+                                   "unit": "agent-steps/s", "avg_launch_us": sd * 1e3 / k,
+                                   "lanes_per_env": sv["lanes_per_env"], "kernel": sv["kernel"],
                                    "roofline": {"bound": "hbm", "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": s_ach / HBM_PEAK_GBS, "traffic": traffic_for(sb),
-                                                "bytes_per_launch": s_bytes}}
-        if fused is not None:
-            line["fused_steps"] = fused
-        if scaled is not None:
-            line["scaled_topology"] = scaled
-        if marl_env is not None:
-            line["pymarl_env"] = marl_env
-        if mappo is not None:
-            line["mappo"] = mappo
-        if ippo is not None:
-            line["ippo_scaled"] = ippo
-        if mappo_scaled is not None:
-            line["mappo_scaled"] = mappo_scaled
-        print(json.dumps(line), flush=True)
+                                                "frac": s_ach / HBM_PEAK_GBS, "traffic": s_traffic,
+                                                "traffic_source": s_src, "bytes_per_launch": s_bytes}}
+        else:
+            line["scale_point"] = res
+    if not args.no_scale_point:
+        line["fused_steps"] = guarded("fused_steps", fused_leg, device, rank, world, B)
+        line["scaled_topology"] = guarded("scaled_topology", scaled_leg, device, rank, world)
+        line["pymarl_env"] = guarded("pymarl_env", marl_env_leg, device, rank, world)
+    if not args.no_mappo:
+        line["mappo"] = guarded("mappo", mappo_leg, device, rank, world, args.mappo_envs)
+        line["ippo_scaled"] = guarded("ippo_scaled", ippo_leg, device, rank, world)
+        line["mappo_scaled"] = guarded("mappo_scaled", ippo_leg, device, rank, world, algorithm="mappo")
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline)
+    timer.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

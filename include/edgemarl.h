@@ -159,6 +159,10 @@ int em_set_lanes_per_env(em_handle *h, int lanes);
  * scalar wavefront, 2..8); 0 restores the automatic choice (5 below 65,536 environments, 8 from there on).  Results
  * do not depend on it. */
 int em_set_workgroup_waves(em_handle *h, int waves);
+/* The variant the next reset/step launch will use (for benchmark and profile labels): lanes a wavefront gives to one
+ * environment (n_nodes in the packed layout) and wavefronts per workgroup after the launch's own clamp.  Returns 1 for
+ * the packed layout, 0 for power-of-two groups, negative on error.  No counterpart in the reference. */
+int em_get_kernel_variant(const em_handle *h, int32_t *lanes_per_env, int32_t *workgroup_waves);
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
     L.em_n_envs.restype = i64
     L.em_set_lanes_per_env.argtypes = [vp, i32]
     L.em_set_workgroup_waves.argtypes = [vp, i32]
+    L.em_get_kernel_variant.argtypes = [vp, vp, vp]
+    L.em_get_kernel_variant.restype = C.c_int
     L.ems_create.argtypes = [C.POINTER(EmConfig), C.c_int32, i64, i32, u64, u64, i64, C.POINTER(vp)]
     L.ems_destroy.argtypes = [vp]
     L.ems_reset.argtypes = [vp, i32, u64, C.POINTER(EmsStepOut), vp]

@@ -1699,6 +1699,18 @@ int em_set_lanes_per_env(em_handle* h, int lanes)
     return EM_OK;
 }
 
+int em_get_kernel_variant(const em_handle* h, int32_t* lanes_per_env, int32_t* workgroup_waves)
+{
+    if (!h) return em::fail(EM_ERR_INVALID, "null handle");
+    const int n = h->cfg.n_nodes;
+    const int epw = 64 / (h->lanes == EM_LANES_PACKED ? n : h->lanes);
+    // the launch clamps the workers so that the scalar wavefront's 64 lanes cover the workgroup's environments
+    const int n_work = (h->wg_waves - 1) * epw <= 64 ? h->wg_waves - 1 : (64 / epw > 0 ? 64 / epw : 1);
+    if (lanes_per_env) *lanes_per_env = h->lanes == EM_LANES_PACKED ? n : h->lanes;
+    if (workgroup_waves) *workgroup_waves = n_work + 1;
+    return h->lanes == EM_LANES_PACKED ? 1 : 0;
+}
+
 int em_set_workgroup_waves(em_handle* h, int waves)
 {
     if (!h) return em::fail(EM_ERR_INVALID, "null handle");

@@ -142,6 +142,15 @@ class BatchedEdgeSimGym:
         """Wavefronts per workgroup of the step kernel (waves - 1 workers + 1 scalar); tuning only."""
         _lib.check(self._L.em_set_workgroup_waves(self._h, int(waves)))
 
+    def kernel_variant(self) -> dict:
+        """Layout the next launch uses (``em_get_kernel_variant``): benchmark/profile labels."""
+        lanes, waves = C.c_int32(0), C.c_int32(0)
+        packed = self._L.em_get_kernel_variant(self._h, C.byref(lanes), C.byref(waves))
+        if packed < 0:
+            _lib.check(packed, "em_get_kernel_variant")
+        return {"lanes_per_env": int(lanes.value), "packed": bool(packed), "workgroup_waves": int(waves.value),
+                "kernel": f"env_kernel<{'packed' if packed else lanes.value},philox,step>"}
+
     @property
     def record_bytes(self) -> int:
         return int(self._L.em_record_bytes(self._h))

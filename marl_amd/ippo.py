@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib, gmlp
-from .config import SCALED_ENV_CONFIG
+from .config import SCALED_ENV_CONFIG, mean_arrivals_bound
 from .env import METRIC_KEYS
 from .env_scaled import PENDING_CAP, ScaledEdgeSimGym
 from .parallel import GradSync
@@ -36,11 +36,14 @@ def _stream(device) -> int:
 class ScaledRolloutStorage:
     """Device buffers of ``ems_rollout``."""
 
-    def __init__(self, n_envs, n_servers, n_deciders, horizon, device, capacity_entries=None, central=False):
+    def __init__(self, n_envs, n_servers, n_deciders, horizon, device, capacity_entries=None, central=False,
+                 entries_per_step=4.0):
+        """``entries_per_step``: bound on the mean number of acting deciders per environment step used to size large
+        batches (``marl_amd.config.mean_arrivals_bound``); small batches get the exact worst case."""
         B, S, D, T = int(n_envs), int(n_servers), int(n_deciders), int(horizon)
-        if capacity_entries is None:   # exact worst case for small batches, 4 acting deciders per env-step otherwise
+        if capacity_entries is None:
             worst = B * T * min(D, PENDING_CAP)
-            capacity_entries = worst if worst <= (1 << 22) else int(B * T * 4)
+            capacity_entries = worst if worst <= (1 << 22) else int(B * T * min(D, PENDING_CAP, entries_per_step)) + B * PENDING_CAP
         self.n_envs, self.n_servers, self.n_deciders, self.horizon, self.device = B, S, D, T, device
         self.capacity_entries = E = int(capacity_entries)
         f32, i32, u8 = torch.float32, torch.int32, torch.uint8
@@ -62,17 +65,26 @@ class ScaledRolloutStorage:
         self.t["k_tb"].zero_()
         self.steps_recorded = 0
 
+    def total_raw(self):
+        """(entries recorded so far, error flag), without raising; synchronises."""
+        return int(self.t["counters"][self.steps_recorded].item()), int(self.t["err_flag"].item())
+
+    def overflow_message(self, entries):
+        return (f"rollout storage capacity exceeded after {entries} entries were recorded (capacity {self.capacity_entries} "
+                f"for {self.n_envs} envs x {self.horizon} steps): construct the trainer with a larger capacity_entries")
+
     def total(self) -> int:
         """Entries recorded so far; synchronises."""
-        if int(self.t["err_flag"].item()) != 0:
-            raise RuntimeError("rollout storage capacity exceeded; construct it with a larger capacity_entries")
-        return int(self.t["counters"][self.steps_recorded].item())
+        e, err = self.total_raw()
+        if err != 0:
+            raise RuntimeError(self.overflow_message(e))
+        return e
 
 
 class IPPO:
     def __init__(self, n_servers, n_deciders, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2, value_loss_coeff=0.5,
                  entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4, device="cuda:0", n_envs=1, horizon=1000,
-                 capacity_entries=None, seed=0, shared=False, process_group=None):
+                 capacity_entries=None, seed=0, shared=False, process_group=None, entries_per_step=4.0):
         self.S, self.D = int(n_servers), int(n_deciders)
         self.G = 1 if shared else self.D
         self.gamma, self.gae_lambda, self.clip_param = gamma, gae_lambda, clip_param
@@ -95,7 +107,9 @@ class IPPO:
         self.m_a, self.v_a = torch.zeros_like(self.actor.flat), torch.zeros_like(self.actor.flat)
         self.m_c, self.v_c = torch.zeros_like(self.critic.flat), torch.zeros_like(self.critic.flat)
         self.step_count = 0
-        self.buffer = ScaledRolloutStorage(n_envs, self.S, self.D, horizon, self.device, capacity_entries)
+        self.entries_per_step = float(entries_per_step)
+        self.buffer = ScaledRolloutStorage(n_envs, self.S, self.D, horizon, self.device, capacity_entries,
+                                           entries_per_step=entries_per_step)
         self.moments = torch.zeros((self.G, 3), dtype=torch.float64, device=self.device)
         self._chain = torch.zeros((int(n_envs), self.D, 2), dtype=torch.float64, device=self.device)
         # workgroups per network: independent learners map one network per CU; a shared network uses the whole chip
@@ -151,26 +165,26 @@ class IPPO:
     def update(self):
         ro = self.buffer
         self.join_value()
-        if ro.steps_recorded == 0:
-            return {}
-        E = ro.total()
-        if E == 0:
-            ro.clear()
+        E = self._global_gate()
+        if E is None:
             return {}
         tt, L, dev = ro.t, self._L, self.device
-        with torch.cuda.device(dev):
-            _lib.check(L.em_gae_agents(ro.n_envs, ro.steps_recorded, self.D, tt["reward_tb"].data_ptr(), tt["done_tb"].data_ptr(),
-                                       tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), tt["ent_agent"].data_ptr(),
-                                       tt["ent_value"].data_ptr(), float(self.gamma), float(self.gae_lambda),
-                                       self._chain.data_ptr(), tt["ent_adv"].data_ptr(), tt["ent_ret"].data_ptr(), _stream(dev)),
-                       "em_gae_agents")
         x = tt["ent_obs"][:E]
-        if self.G > 1:
-            off, perm = gmlp.group_index(tt["ent_agent"][:E], self.G)      # stable: fixed summation order per learner
-        else:
-            off = torch.tensor([0, E], dtype=torch.int64, device=dev)
-            perm = None
-        gmlp.group_moments(tt["ent_adv"], off, perm, self.G, self.moments)
+        if E > 0:
+            with torch.cuda.device(dev):
+                _lib.check(L.em_gae_agents(ro.n_envs, ro.steps_recorded, self.D, tt["reward_tb"].data_ptr(), tt["done_tb"].data_ptr(),
+                                           tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), tt["ent_agent"].data_ptr(),
+                                           tt["ent_value"].data_ptr(), float(self.gamma), float(self.gae_lambda),
+                                           self._chain.data_ptr(), tt["ent_adv"].data_ptr(), tt["ent_ret"].data_ptr(), _stream(dev)),
+                           "em_gae_agents")
+            if self.G > 1:
+                off, perm = gmlp.group_index(tt["ent_agent"][:E], self.G)      # stable: fixed summation order per learner
+            else:
+                off = torch.tensor([0, E], dtype=torch.int64, device=dev)
+                perm = None
+            gmlp.group_moments(tt["ent_adv"], off, perm, self.G, self.moments)
+        else:                                # empty shard: zero moments, zero gradients, every collective still joined
+            self.moments.zero_()
         n_global = self._sum_moments()       # per-learner moments, summed over ranks
         na, nc = self.actor.n_per, self.critic.n_per
         sa, sc = self.actor.slab_floats(), self.critic.slab_floats()
@@ -180,11 +194,15 @@ class IPPO:
             self._slab_c = torch.empty(rows * sc, dtype=torch.float32, device=dev)
         acc = torch.zeros(6, dtype=torch.float64, device=dev)
         for _ in range(int(self.num_sgd_iter)):
-            gmlp.actor_grad(self.actor, x, tt["ent_action"], tt["ent_logp"], tt["ent_adv"], self.moments, self.g_actor,
-                            self.l_actor, self._slab_a, off, perm, self.split, self.clip_param, self.entropy_coeff)
-            gmlp.critic_grad(self.critic, x, tt["ent_ret"], self.moments, self.g_critic, self.l_critic, self._slab_c, off, perm,
-                             self.split, self.value_loss_coeff)
-            if self.sync.enabled and self.sync.world_size > 1:   # the one data-path collective per epoch
+            if E > 0:
+                gmlp.actor_grad(self.actor, x, tt["ent_action"], tt["ent_logp"], tt["ent_adv"], self.moments, self.g_actor,
+                                self.l_actor, self._slab_a, off, perm, self.split, self.clip_param, self.entropy_coeff)
+                gmlp.critic_grad(self.critic, x, tt["ent_ret"], self.moments, self.g_critic, self.l_critic, self._slab_c, off,
+                                 perm, self.split, self.value_loss_coeff)
+            else:
+                for buf in (self.g_actor, self.l_actor, self.g_critic, self.l_critic):
+                    buf.zero_()
+            if self.sync.active:   # the one data-path collective per epoch
                 g = self.grads
                 g[:, :na] = self.g_actor; g[:, na:na + 3] = self.l_actor
                 g[:, na + 3:na + 3 + nc] = self.g_critic; g[:, na + 3 + nc:] = self.l_critic
@@ -204,6 +222,22 @@ class IPPO:
         self.last_update = {"actor_loss": float(-s[0] / k), "critic_loss": float(0.5 * s[3] / k), "entropy": float(s[1] / k),
                             "transitions": n_global}
         return dict(self.last_update)
+
+    def _global_gate(self):
+        """Entries of this rank, or None when NO rank recorded anything.  The decisions that would leave update() before a
+        collective are taken on global totals: an overflow on one rank raises on all, a rank with an empty shard goes on
+        (its kernels see zero rows, its gradient slabs reduce to zeros) and joins every all-reduce."""
+        ro = self.buffer
+        E, err = ro.total_raw() if ro.steps_recorded else (0, 0)
+        E_g, err_g = self.sync.sum_counts([E, err], self.device)
+        if err_g:
+            msg = ro.overflow_message(E) if err else "rollout storage capacity exceeded on another rank"
+            ro.clear()
+            raise RuntimeError(msg)
+        if E_g == 0:
+            ro.clear()
+            return None
+        return E
 
     def _sum_moments(self) -> int:
         self.sync.sum_grads(self.moments)          # plain SUM over ranks of the [G, 3] float64 moments
@@ -243,14 +277,16 @@ class IPPOTrainer:
                                     latency_log_capacity=0)
         self.S, self.D = self.env.n_nodes, self.env.n_deciders
         self.algorithm = algorithm
+        eps_bound = mean_arrivals_bound(cfg)
         if algorithm == "mappo":
             from .mappo_scaled import ScaledMAPPO
             self.algo = ScaledMAPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
-                                    capacity_entries=capacity_entries, seed=self.seed, process_group=process_group)
+                                    capacity_entries=capacity_entries, seed=self.seed, process_group=process_group,
+                                    entries_per_step=eps_bound)
         elif algorithm in ("ippo", "shared"):
             self.algo = IPPO(self.S, self.D, device=self.device, n_envs=self.n_envs, horizon=self.env.episode_len,
                              capacity_entries=capacity_entries, seed=self.seed, shared=algorithm == "shared",
-                             process_group=process_group)
+                             process_group=process_group, entries_per_step=eps_bound)
         else:
             raise ValueError(f"unknown algorithm {algorithm!r}")
         self.placement = torch.zeros((self.n_envs, PENDING_CAP), dtype=torch.int32, device=self.device)

@@ -169,13 +169,16 @@ class HipAdam:
 class RolloutStorage:
     """Device buffers of ``em_rollout`` for one batch of episodes (RolloutBuffer, mappo_algorithm.py:93-131)."""
 
-    def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None):
+    def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None, entries_per_step=2.2):
+        """``entries_per_step``: bound on the MEAN number of acting agents per environment step used to size large
+        batches (small ones get the exact worst case n_nodes); :func:`marl_amd.config.mean_arrivals_bound` derives it
+        from the arrival-rate range and the time-step clip of an ENV_CONFIG."""
         B, n, T = int(n_envs), int(n_nodes), int(horizon)
         w, A = n + 4, n + 1
         if capacity_steps is None:
             capacity_steps = B * T
-        if capacity_entries is None:   # exact worst case for small batches, 2.2 acting agents per env-step otherwise
-            capacity_entries = B * T * n if B * T * n <= (1 << 22) else int(B * T * 2.2)
+        if capacity_entries is None:   # exact worst case for small batches, `entries_per_step` per env-step otherwise
+            capacity_entries = B * T * n if B * T * n <= (1 << 22) else int(B * T * min(n, entries_per_step)) + B * n
         self.n_envs, self.n_nodes, self.horizon, self.device = B, n, T, device
         self.capacity_entries, self.capacity_steps = int(capacity_entries), int(capacity_steps)
         E, S = self.capacity_entries, self.capacity_steps
@@ -196,12 +199,22 @@ class RolloutStorage:
         self.t["k_tb"].zero_()
         self.steps_recorded = 0
 
+    def totals_raw(self):
+        """(entries, steps, error flag) recorded so far, without raising; synchronises."""
+        c = self.t["counters"][self.steps_recorded].tolist()
+        return int(c[0]), int(c[2]), int(self.t["err_flag"].item())
+
+    def overflow_message(self, entries, steps):
+        return (f"rollout storage capacity exceeded after {entries} entries / {steps} steps were recorded (capacity "
+                f"{self.capacity_entries} entries, {self.capacity_steps} steps for {self.n_envs} envs x {self.horizon} "
+                "steps): construct RolloutStorage / MAPPOTrainer with a larger capacity_entries")
+
     def totals(self):
         """(entries, steps) recorded so far; synchronises."""
-        c = self.t["counters"][self.steps_recorded].tolist()
-        if int(self.t["err_flag"].item()) != 0:
-            raise RuntimeError("rollout storage capacity exceeded; construct RolloutStorage with larger capacities")
-        return int(c[0]), int(c[2])
+        e, s, err = self.totals_raw()
+        if err != 0:
+            raise RuntimeError(self.overflow_message(e, s))
+        return e, s
 
     def __len__(self):
         return self.totals()[0]
@@ -213,7 +226,7 @@ class MAPPO:
 
     def __init__(self, obs_dim, state_dim, action_dim, n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
                  value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4, device="cuda:0",
-                 n_envs=1, horizon=1000, process_group=None):
+                 n_envs=1, horizon=1000, process_group=None, capacity_entries=None, entries_per_step=2.2):
         self.obs_dim, self.state_dim, self.action_dim, self.n_agents = obs_dim, state_dim, action_dim, n_agents
         self.gamma, self.gae_lambda, self.clip_param = gamma, gae_lambda, clip_param
         self.value_loss_coeff, self.entropy_coeff = value_loss_coeff, entropy_coeff
@@ -237,7 +250,8 @@ class MAPPO:
         self.actor_optimizer = HipAdam(self.actor, lr)
         self.critic_optimizer = HipAdam(self.critic, lr)
         self.value_normalizer = ValueNormalizer(1, device=self.device)
-        self.buffer = RolloutStorage(n_envs, n_agents, horizon, self.device)
+        self.buffer = RolloutStorage(n_envs, n_agents, horizon, self.device, capacity_entries=capacity_entries,
+                                     entries_per_step=entries_per_step)
         self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._gae_partials = torch.zeros(3 * ((n_envs + 255) // 256), dtype=torch.float64, device=self.device)
         self._slab_a = self._slab_c = None
@@ -314,13 +328,22 @@ class MAPPO:
 
     def update(self):
         ro = self.buffer
-        if ro.steps_recorded == 0:
-            return {}
-        E, S = ro.totals()
-        if E == 0:
+        # Every decision that would leave before a collective is taken on GLOBAL totals, so all ranks return, raise or
+        # go on together: a rank whose shard recorded nothing still joins every all-reduce (with zero gradients), and an
+        # overflow on one rank raises on all of them instead of leaving the others waiting in all_reduce.
+        E, S, err = ro.totals_raw() if ro.steps_recorded else (0, 0, 0)
+        recorded_g, E_g, err_g = self.sync.sum_counts([ro.steps_recorded, E, err], self.device)
+        if err_g:
+            msg = ro.overflow_message(E, S) if err else "rollout storage capacity exceeded on another rank"
+            ro.clear()
+            raise RuntimeError(msg)
+        if recorded_g == 0 or E_g == 0:
             ro.clear()
             return {}
-        self.compute_gae()
+        if ro.steps_recorded:
+            self.compute_gae()
+        else:
+            self.moments.zero_()
         n_global = self.sync.sum_moments(self.moments)   # global advantage moments and transition count
         L = self._L
         na, nc = self.n_actor, self.n_critic
@@ -341,15 +364,10 @@ class MAPPO:
             s = _stream(self.device)
             for _ in range(int(self.num_sgd_iter)):
                 a_net, c_net = self.actor.net(), self.critic.net()
-                _lib.check(L.em_ppo_actor_grad(C.byref(a_net), self.actor.log_std.data_ptr(), t["ent_obs"].data_ptr(),
-                                               t["ent_action"].data_ptr(), t["ent_logp"].data_ptr(), t["ent_adv"].data_ptr(),
-                                               self.moments.data_ptr(), E, n_global, float(self.clip_param),
-                                               float(self.entropy_coeff), self._slab_a.data_ptr(), wa, g.data_ptr(),
-                                               loss_a.data_ptr(), s), "em_ppo_actor_grad")
-                _lib.check(L.em_ppo_critic_grad(C.byref(c_net), t["st_state"].data_ptr(), t["st_first"].data_ptr(),
-                                                t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
-                                                float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
-                                                g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
+                if E == 0:             # empty shard: contributes zero gradients and loss sums to the all-reduce
+                    g.zero_()
+                else:
+                    self._local_grads(L, a_net, c_net, t, E, S, n_global, mean, var, wa, wc, g, loss_a, loss_c, s)
                 self.sync.sum_grads(g)   # the one data-path collective per epoch: gradient-of-sums + loss sums
                 self.actor_optimizer.step_count += 1
                 self.critic_optimizer.step_count += 1
@@ -369,6 +387,19 @@ class MAPPO:
                             "entropy": float(sums[1] / k), "transitions": n_global}
         return {"actor_loss": self.last_update["actor_loss"], "critic_loss": self.last_update["critic_loss"],
                 "entropy": self.last_update["entropy"]}
+
+    def _local_grads(self, L, a_net, c_net, t, E, S, n_global, mean, var, wa, wc, g, loss_a, loss_c, s):
+        """This rank's gradient-of-sums of one epoch into ``g`` (actor | critic | loss sums)."""
+        na = self.n_actor
+        _lib.check(L.em_ppo_actor_grad(C.byref(a_net), self.actor.log_std.data_ptr(), t["ent_obs"].data_ptr(),
+                                       t["ent_action"].data_ptr(), t["ent_logp"].data_ptr(), t["ent_adv"].data_ptr(),
+                                       self.moments.data_ptr(), E, n_global, float(self.clip_param),
+                                       float(self.entropy_coeff), self._slab_a.data_ptr(), wa, g.data_ptr(),
+                                       loss_a.data_ptr(), s), "em_ppo_actor_grad")
+        _lib.check(L.em_ppo_critic_grad(C.byref(c_net), t["st_state"].data_ptr(), t["st_first"].data_ptr(),
+                                        t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
+                                        float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
+                                        g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
 
     # -- dict-API conveniences of the reference (mappo_algorithm.py:189-239), tiny batches ---------------------
     def get_values(self, state):

@@ -50,7 +50,8 @@ class ScaledMAPPO(IPPO):
         super().__init__(n_servers, n_deciders, device=device, n_envs=n_envs, horizon=horizon, capacity_entries=1, seed=seed,
                          shared=True, process_group=process_group, **hyper)
         dev = self.device
-        self.buffer = ScaledRolloutStorage(n_envs, self.S, self.D, horizon, dev, capacity_entries, central=True)
+        self.buffer = ScaledRolloutStorage(n_envs, self.S, self.D, horizon, dev, capacity_entries, central=True,
+                                           entries_per_step=self.entries_per_step)
         self.critic = CentralCritic(self.D, self.S + 4, dev, seed=2 * seed + 1)
         nc = self.critic.n_per
         self.g_critic = torch.zeros((1, nc), dtype=torch.float32, device=dev)
@@ -98,11 +99,8 @@ class ScaledMAPPO(IPPO):
     def update(self):
         ro = self.buffer
         self.join_value()
-        if ro.steps_recorded == 0:
-            return {}
-        E = ro.total()
-        if E == 0:
-            ro.clear()
+        E = self._global_gate()
+        if E is None:
             return {}
         tt, L, dev, T, B = ro.t, self._L, self.device, ro.steps_recorded, ro.n_envs
         # MAPPO.compute_gae over each environment's flattened list (em_gae reads the dense [T][B] arrays)
@@ -116,7 +114,8 @@ class ScaledMAPPO(IPPO):
         n_global = self.sync.sum_moments(self.moments)
         x = tt["ent_obs"][:E]
         off_a = torch.tensor([0, E], dtype=torch.int64, device=dev)
-        off_c, perm_c = gmlp.group_index(tt["ent_agent"][:E], self.D)      # stable: fixed summation order per decider block
+        if E > 0:
+            off_c, perm_c = gmlp.group_index(tt["ent_agent"][:E], self.D)  # stable: fixed summation order per decider block
         cc = self.critic.struct()
         n_states = T * B
         if self._dz is None or self._dz.shape[0] < n_states:
@@ -129,18 +128,22 @@ class ScaledMAPPO(IPPO):
         na, nc = self.actor.n_per, self.critic.n_per
         mom = self.moments.view(1, 3)
         acc = torch.zeros(6, dtype=torch.float64, device=dev)
-        part = self._partials(E)
+        part = self._partials(max(E, 1))
         for _ in range(int(self.num_sgd_iter)):
-            gmlp.actor_grad(self.actor, x, tt["ent_action"], tt["ent_logp"], tt["ent_adv"], mom, self.g_actor, self.l_actor,
-                            self._slab_a, off_a, None, self.split, self.clip_param, self.entropy_coeff)
-            cc = self.critic.struct()
-            with torch.cuda.device(dev):
-                _lib.check(L.em_cc_grad(C.byref(cc), x.data_ptr(), tt["ent_state"].data_ptr(), tt["ent_ret"].data_ptr(),
-                                        off_c.data_ptr(), perm_c.data_ptr(), self.cc_split, part.data_ptr(), n_states,
-                                        tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), n_global, float(self.value_loss_coeff),
-                                        0.0, 1.0, self._dz.data_ptr(), self._cc_slab.data_ptr(), self.g_critic.data_ptr(),
-                                        self.l_critic.data_ptr(), _stream(dev)), "em_cc_grad")
-            if self.sync.enabled and self.sync.world_size > 1:
+            if E == 0:                       # empty shard: zero contributions, every collective still joined
+                for buf in (self.g_actor, self.l_actor, self.g_critic, self.l_critic):
+                    buf.zero_()
+            else:
+                gmlp.actor_grad(self.actor, x, tt["ent_action"], tt["ent_logp"], tt["ent_adv"], mom, self.g_actor, self.l_actor,
+                                self._slab_a, off_a, None, self.split, self.clip_param, self.entropy_coeff)
+                cc = self.critic.struct()
+                with torch.cuda.device(dev):
+                    _lib.check(L.em_cc_grad(C.byref(cc), x.data_ptr(), tt["ent_state"].data_ptr(), tt["ent_ret"].data_ptr(),
+                                            off_c.data_ptr(), perm_c.data_ptr(), self.cc_split, part.data_ptr(), n_states,
+                                            tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), n_global,
+                                            float(self.value_loss_coeff), 0.0, 1.0, self._dz.data_ptr(), self._cc_slab.data_ptr(),
+                                            self.g_critic.data_ptr(), self.l_critic.data_ptr(), _stream(dev)), "em_cc_grad")
+            if self.sync.active:
                 gg = self.grads
                 gg[:, :na] = self.g_actor; gg[:, na:na + 3] = self.l_actor
                 gg[:, na + 3:na + 3 + nc] = self.g_critic; gg[:, na + 3 + nc:] = self.l_critic[:1]

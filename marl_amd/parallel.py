@@ -16,13 +16,21 @@ import torch
 
 
 class GradSync:
-    def __init__(self, process_group=None, enabled=None):
+    def __init__(self, process_group=None, enabled=None, always=None):
+        """``always``: issue the collectives even in a one-rank group (default: environment variable
+        EDGEMARL_SYNC_ALWAYS=1).  A one-GPU box can then execute the production backend's call path (RCCL all-reduce
+        ordered against the kernels this library launches on torch's current stream); results are unchanged."""
+        import os
+
         import torch.distributed as dist
         self.dist = dist
         self.group = process_group
         self.enabled = (dist.is_available() and dist.is_initialized()) if enabled is None else bool(enabled)
         self.world_size = dist.get_world_size(process_group) if self.enabled else 1
         self.rank = dist.get_rank(process_group) if self.enabled else 0
+        if always is None:
+            always = os.environ.get("EDGEMARL_SYNC_ALWAYS", "0") == "1"
+        self.active = self.enabled and (self.world_size > 1 or bool(always))
         # gloo (the CPU test rig; production is "nccl" = RCCL) stages device tensors through the host from its own
         # threads: with kernels still in flight on the caller's stream that was seen to deadlock two ranks sharing one
         # GPU (both stuck inside all_reduce), so the stream is drained first.  RCCL orders itself on the stream.
@@ -34,19 +42,31 @@ class GradSync:
 
     def sum_moments(self, moments: torch.Tensor) -> int:
         """In-place SUM over ranks; returns the global transition count."""
-        if self.enabled and self.world_size > 1:
+        if self.active:
             self._ready(moments)
             self.dist.all_reduce(moments, op=self.dist.ReduceOp.SUM, group=self.group)
         return int(round(float(moments[0].item())))
 
+    def sum_counts(self, values, device) -> list:
+        """SUM over ranks of a few host integers (transition count, error flag ...): every rank gets the same totals, so
+        rank-local decisions that would skip a later collective (an empty shard, a full buffer) are taken by ALL ranks
+        together or by none."""
+        vals = [int(v) for v in values]
+        if not self.active:
+            return vals
+        t = torch.tensor(vals, dtype=torch.int64, device=device)
+        self._ready(t)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.tolist()]
+
     def sum_grads(self, flat: torch.Tensor) -> None:
-        if self.enabled and self.world_size > 1:
+        if self.active:
             self._ready(flat)
             self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, flat: torch.Tensor, src: int = 0) -> None:
         """Replicas start from rank src's parameters (seeded init is already identical; this is a safety net)."""
-        if self.enabled and self.world_size > 1:
+        if self.active:
             self._ready(flat)
             self.dist.broadcast(flat, src=src, group=self.group)
 

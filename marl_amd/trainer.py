@@ -6,10 +6,12 @@ episode buffer.  Multi-GPU: one process per GPU, environments sharded by rank, g
 ``MAPPO.update`` (RCCL)."""
 from __future__ import annotations
 
+import sys
+
 import numpy as np
 import torch
 
-from .config import ENV_CONFIG
+from .config import ENV_CONFIG, mean_arrivals_bound
 from .env import METRIC_KEYS, BatchedEdgeSimGym
 from .mappo import MAPPO, RolloutStorage
 
@@ -18,7 +20,7 @@ _STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tp
 
 class MAPPOTrainer:
     def __init__(self, env_config, seed=0, device="cuda:0", n_envs=1, rank=0, world_size=1, process_group=None,
-                 verbose=True, update_interval=1):
+                 verbose=True, update_interval=1, capacity_entries=None):
         if str(device) == "cuda":
             device = "cuda:0"
         self.device = torch.device(device)
@@ -47,7 +49,8 @@ class MAPPOTrainer:
                            n_agents=self.n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
                            value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4,
                            device=self.device, n_envs=self.n_envs,
-                           horizon=self.env.episode_len * max(1, int(update_interval)), process_group=process_group)
+                           horizon=self.env.episode_len * max(1, int(update_interval)), process_group=process_group,
+                           capacity_entries=capacity_entries, entries_per_step=mean_arrivals_bound(cfg))
         self.update_interval = max(1, int(update_interval))   # episodes the rollout storage can hold before update()
         B, n = self.n_envs, self.n_agents
         self.placement = torch.zeros((B, n), dtype=torch.int32, device=self.device)
@@ -116,6 +119,14 @@ class MAPPOTrainer:
         for k in _STAT_KEYS:
             stats[k] = float(mean[idx[k]])
         stats["per_env"] = {"episode_reward": total_reward, "metrics": metrics}
+        if record_buffer:
+            # a full storage is reported here, where the episode's statistics are fetched anyway; the error itself is raised by
+            # mappo.update() on ALL ranks together (a rank-local raise in front of a collective would strand the others)
+            e, s_, err = ro.totals_raw()
+            stats["storage_overflow"] = bool(err)
+            if err:
+                print("[marl_amd] " + ro.overflow_message(e, s_) + "; this batch is incomplete and update() will raise",
+                      file=sys.stderr, flush=True)
         return stats
 
     def train(self, num_iterations=1000, update_interval=1, eval_interval=10, eval_episodes=10, max_total_steps=5_000_000):

@@ -51,6 +51,102 @@ def test_two_ranks_match_one_process(tmp_path):
     np.testing.assert_allclose(p0, single, rtol=2e-4, atol=2e-6)
 
 
+# ---- a rank whose shard records nothing must still join every collective (no deadlock, no early return) ------------------
+def _empty_cfg():
+    cfg = _cfg()
+    cfg.update(task_arrival_rate=1e-9, task_arrival_rate_range=(1e-9, 1e-9))      # Poisson(1e-9 dt): never an arrival
+    return cfg
+
+
+def _empty_shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg() if rank == 0 else _empty_cfg(), seed=3, device="cuda:0", n_envs=6, rank=0, world_size=world,
+                      verbose=False)
+    tr.train_episode(explore=True, record_buffer=True)
+    e_local = tr.mappo.buffer.totals()[0]
+    out = tr.mappo.update()
+    np.save(os.path.join(out_dir, f"empty_{rank}.npy"), tr.mappo.flat_params.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, f"empty_meta_{rank}.npy"), np.array([e_local, tr.mappo.last_update["transitions"],
+                                                                      out["critic_loss"]]))
+    dist.destroy_process_group()
+
+
+def test_rank_with_empty_shard_joins_the_collectives(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_empty_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)     # a deadlock would hang here
+    p0, p1 = (np.load(tmp_path / f"empty_{r}.npy") for r in range(2))
+    m0, m1 = (np.load(tmp_path / f"empty_meta_{r}.npy") for r in range(2))
+    assert m1[0] == 0 and m0[0] > 0 and m0[1] == m1[1] == m0[0]      # rank 1 recorded nothing; both saw the global count
+    assert np.array_equal(p0, p1)                                     # replicas stay identical
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=6, verbose=False)
+    tr.train_episode(explore=True, record_buffer=True)
+    out = tr.mappo.update()
+    assert np.array_equal(p0, tr.mappo.flat_params.detach().cpu().numpy())    # zeros added to the sums change nothing
+    assert out["critic_loss"] == m0[2]
+
+
+def _overflow_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=6, rank=rank, world_size=world, verbose=False,
+                      capacity_entries=8 if rank == 1 else None)          # rank 1's storage overflows in the first steps
+    raised = ""
+    try:
+        tr.train_episode(explore=True, record_buffer=True)
+        tr.mappo.update()
+    except RuntimeError as e:
+        raised = str(e)
+    open(os.path.join(out_dir, f"overflow_{rank}.txt"), "w").write(raised)
+    dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_raises_on_all(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_overflow_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = (open(tmp_path / f"overflow_{r}.txt").read() for r in range(2))
+    assert "another rank" in m0 and "capacity 8 entries" in m1
+
+
+# ---- the production backend on one rank: RCCL all-reduce ordered against this library's kernels ---------------------------
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      EDGEMARL_SYNC_ALWAYS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=B_TOTAL, rank=0, world_size=1, verbose=False)
+    assert tr.mappo.sync.active and not tr.mappo.sync._drain
+    np.save(os.path.join(out_dir, "rccl.npy"), _run(tr))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_equals_no_collective(tmp_path):
+    """backend "nccl" (= RCCL) with the collectives forced on in a one-rank group: every all_reduce of MAPPO.update runs
+    on RCCL's stream, ordered by torch against the kernels this library queued on the current stream through raw stream
+    handles.  A sum over one rank must leave every bit as it was."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    from marl_amd.trainer import MAPPOTrainer
+    single = _run(MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=B_TOTAL, verbose=False))
+    assert np.array_equal(np.load(tmp_path / "rccl.npy"), single)
+
+
 # ---- independent PPO on the scaled topology (marl_amd/ippo.py) -------------------------------------------------------
 def _scaled_cfg():
     from marl_amd.config import SCALED_ENV_CONFIG

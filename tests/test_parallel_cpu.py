@@ -87,3 +87,59 @@ def test_shard_range_partitions():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _counts_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.parallel import GradSync
+    got = GradSync().sum_counts([100, 0, 0] if rank == 0 else [100, 7, 8], torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"counts_{rank}.npy"), np.array(got))
+    dist.destroy_process_group()
+
+
+def test_sum_counts_gives_every_rank_the_global_totals(tmp_path):
+    """The gate of MAPPO.update / IPPO.update: a rank with an empty shard (0 entries) or an overflow flag elsewhere sees the
+    same totals as its peers, so all ranks take the same branch before the first gradient collective."""
+    mp.spawn(_counts_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = (np.load(tmp_path / f"counts_{r}.npy") for r in range(2))
+    assert c0.tolist() == c1.tolist() == [200, 7, 8]
+    from marl_amd.parallel import GradSync
+    assert GradSync(enabled=False).sum_counts([3, 0], torch.device("cpu")) == [3, 0]      # single process: identity
+
+
+def test_bench_launcher_builds_the_rank_command():
+    """`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N ranks as children through
+    torch.distributed.run with the same argv; the parent makes no GPU call."""
+    import sys
+
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "50", "--warmup", "5"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "50", "--warmup", "5"]
+    assert 1024 < bench.free_port() < 65536
+
+
+def test_bench_parent_launches_children_and_passes_exit_code(monkeypatch):
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None, cwd=None):
+        seen.update(cmd=cmd, env=env)
+        return 7
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "2", "--no-cpu-baseline"])
+    try:
+        bench.main()
+        raise AssertionError("the parent must exit with the children's code")
+    except SystemExit as e:
+        assert e.code == 7
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["cmd"][-3:] == ["--gpus", "2", "--no-cpu-baseline"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
