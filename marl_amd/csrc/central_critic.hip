@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
     __syncthreads();
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 gW2[4][4], gW3[4], gb1[4], gb2[4];
-    float gb3 = 0.0f, loss_sum = 0.0f, cnt_sum = 0.0f;
+    float gb3 = 0.0f, cnt_sum = 0.0f;
+    double loss_sum = 0.0;          // float64 per lane (see mappo_bwd.hip)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
             for (int j = 0; j < k; ++j) {          // the state's k transitions share its value (mappo_algorithm.py:303,312-314)
                 const float e = (y[0] - a.norm_mean) / a.norm_scale - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
                 gsum += e;
-                loss_sum += e * e;
+                loss_sum += (double)(e * e);
             }
             cnt_sum += (float)k;
             dy[0] = a.vcoef * a.inv_L * gsum / a.norm_scale;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
                 out[HS_B2 + 16 * t + 4 * q + r] = gb2[t][r];
             }
     }
-    if (lane == 0) { out[HS_B3] = gb3; out[HS_LOSS] = loss_sum; out[HS_LOSS + 1] = 0.0f; out[HS_LOSS + 2] = cnt_sum; }
+    if (lane == 0) { out[HS_B3] = gb3; out[HS_LOSS] = (float)loss_sum; out[HS_LOSS + 1] = 0.0f; out[HS_LOSS + 2] = cnt_sum; }
 }
 
 // dW1[j][d*W + i] += sum over the entries e of decider d of dZ1[state(e)][j] * obs[e][i]; one slab row [64][W] per wavefront

@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         for (int t = 0; t < 4; ++t) gW3[ot][t] = zero4;
         gb3[ot] = zero4; gls[ot] = zero4;
     }
-    float loss_sum = 0.0f, aux_sum = 0.0f, cnt_sum = 0.0f;
+    // loss sums in float64 per lane: a float32 accumulator that adds one row's (nearly constant) entropy a few thousand times
+    // rounds the same way every time and drifted 2e-5 relative at 54 M transitions (tests/test_fullsize_gpu.py)
+    double loss_sum = 0.0, aux_sum = 0.0;
+    float cnt_sum = 0.0f;
 
     // the group's own batch statistics: PPO normalises advantages over the learner's batch (mappo_algorithm.py:293)
     const double m_n = a.moments[3 * g], m_s1 = a.moments[3 * g + 1], m_s2 = a.moments[3 * g + 2];
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 // d min(s1,s2)/d ratio with autograd's tie rule (equal inputs share the gradient)
                 const float wgt = su1 < su2 ? 1.0f : (su1 == su2 ? 0.5f + 0.5f * in_range : in_range);
                 g_lp = -(A * ratio * wgt) * inv_L;                          // d(-mean(min))/d logp
-                if (q == 0) { loss_sum += fminf(su1, su2); cnt_sum += 1.0f; aux_sum += ent_row; }
+                if (q == 0) { loss_sum += (double)fminf(su1, su2); cnt_sum += 1.0f; aux_sum += (double)ent_row; }
             }
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
             for (int ot = 0; ot < OT; ++ot) dy[ot] = zero4;
             if (valid && q == 0) {
                 const float e = (y[0][0] - a.norm_mean) / a.norm_scale - (p_ret - a.norm_mean) / a.norm_scale;   // :312-314
-                loss_sum += e * e;
+                loss_sum += (double)(e * e);
                 cnt_sum += 1.0f;
                 dy[0][0] = a.vcoef * inv_L * e / a.norm_scale;              // d(vcoef * 0.5 * mean(e^2)) / dv
             }
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     if constexpr (ACTOR) out[o_ls + 16 * ot + 4 * q + r] = gls[ot][r];
                 }
     }
-    if (lane == 0) { out[o_loss] = loss_sum; out[o_loss + 1] = aux_sum; out[o_loss + 2] = cnt_sum; }
+    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)aux_sum; out[o_loss + 2] = cnt_sum; }
 }
 
 // grads[g][p] = sum over the group's slab rows, fixed order; the last 3 columns (loss sums) go to loss3[g]

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         gW3[t] = zero4;
     }
     gb3 = zero4; gls = zero4;
-    float loss_sum = 0.0f, aux_sum = 0.0f, cnt_sum = 0.0f;
+    // loss sums in float64 per lane: a float32 accumulator that adds one row's (nearly constant) entropy a few thousand times
+    // rounds the same way every time and drifted 2e-5 relative at 54 M transitions (tests/test_fullsize_gpu.py)
+    double loss_sum = 0.0, aux_sum = 0.0;
+    float cnt_sum = 0.0f;
 
     float adv_mean = 0.0f, adv_den = 1.0f, sd[4] = {1.f, 1.f, 1.f, 1.f}, ls[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (ACTOR) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                 // d min(s1,s2)/d ratio with autograd's tie rule (equal inputs share the gradient)
                 const float wgt = su1 < su2 ? 1.0f : (su1 == su2 ? 0.5f + 0.5f * in_range : in_range);
                 g_lp = -(A * ratio * wgt) * a.inv_L;                        // d(-mean(min))/d logp
-                if (q == 0) { loss_sum += fminf(su1, su2); cnt_sum += 1.0f; }
+                if (q == 0) { loss_sum += (double)fminf(su1, su2); cnt_sum += 1.0f; }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     gls[r] += g_lp * (d[r] * d[r] * iv - 1.0f) - a.ecoef * a.inv_L;   // d logp / d log_std ; entropy bonus
                 }
             }
-            if (valid && q == 0) aux_sum += ent_row;
+            if (valid && q == 0) aux_sum += (double)ent_row;
         } else {
             if (valid && q == 0) {
                 const float v = y[0];
@@ -477,13 +480,13 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     if (j < k) {
                         const float e = vn - p_ret[j];
                         gsum += e;
-                        loss_sum += e * e;                                  // :314 before the 0.5 and the mean
+                        loss_sum += (double)(e * e);                                  // :314 before the 0.5 and the mean
                     }
                 }
                 for (int j = KPRE; j < k; ++j) {
                     const float e = vn - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
                     gsum += e;
-                    loss_sum += e * e;
+                    loss_sum += (double)(e * e);
                 }
                 cnt_sum += (float)k;
                 dy[0] = a.vcoef * a.inv_L * gsum / a.norm_scale;            // d(vcoef * 0.5 * mean(e^2)) / dv
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                 if constexpr (ACTOR) out[o_ls + 4 * q + r] = gls[r];
             }
     }
-    if (lane == 0) { out[o_loss] = loss_sum; out[o_loss + 1] = aux_sum; out[o_loss + 2] = cnt_sum; }
+    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)aux_sum; out[o_loss + 2] = cnt_sum; }
 }
 
 // grads[p] = sum over slab rows in a fixed order (bitwise reproducible): a workgroup owns 32 columns; its 8 row groups sum

@@ -130,3 +130,64 @@ def poisson_mult(block_of, lam):
             i += 1
         else:
             return count
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Policy noise of the throughput mode: the counterpart of Normal(mu, sigma).rsample() in MAPPO.get_actions
+# (mappo_algorithm.py:206-213) when em_policy_step / em_gmlp_policy run with noise == NULL.  Component o of the action of
+# (global env, episode, step, agent) is a Box-Muller normal from Philox block
+#     (env, episode, step, (P_NOISE << 24) | (agent << agent_shift) | (o // 4))          key = seed
+# (agent_shift 4 in mappo_fwd.hip: out_dim <= 16; 8 in gmlp.hip: out_dim <= 80): words (0, 1) of the block give
+# components 4*(o//4) + {0, 1} (cosine, sine branch), words (2, 3) give + {2, 3}.  float32 arithmetic as in the kernels;
+# the device's logf/sincosf are not bit-reproducible on the host, so this restatement pins the stream to ~1e-6, the
+# float32 rounding of the transcendental functions.
+# ---------------------------------------------------------------------------------------------------------------------
+def _unit24(word):
+    return ((word >> 8) + 0.5) / 16777216.0
+
+
+def box_muller(a, b):
+    """Two standard normals from two 32-bit words."""
+    u1, u2 = _unit24(a), _unit24(b)
+    rad = math.sqrt(-2.0 * math.log(u1))
+    return rad * math.cos(TWO_PI * u2), rad * math.sin(TWO_PI * u2)
+
+
+def policy_noise(seed, env, episode, step, agent, out_dim, agent_shift=4):
+    """eps[out_dim] of one (env, episode, step, agent); slow scalar form."""
+    out = []
+    for blk_i in range((out_dim + 3) // 4):
+        blk = block(seed, env, episode, step, P_NOISE, (agent << agent_shift) | blk_i)
+        out.extend(box_muller(blk[0], blk[1]) + box_muller(blk[2], blk[3]))
+    return out[:out_dim]
+
+
+def policy_noise_np(seed, env, episode, step, agent, out_dim, agent_shift=4):
+    """Vectorised form over arrays env/step/agent (numpy, uint64 lanes): returns float32 [len(env), out_dim]."""
+    import numpy as np
+    env = np.asarray(env, np.uint64) & np.uint64(MASK)
+    step = np.asarray(step, np.uint64) & np.uint64(MASK)
+    agent = np.asarray(agent, np.uint64)
+    n = env.shape[0]
+    out = np.empty((n, 4 * ((out_dim + 3) // 4)), np.float32)
+    m0, m1, msk = np.uint64(M0), np.uint64(M1), np.uint64(MASK)
+    for blk_i in range((out_dim + 3) // 4):
+        c0 = env.copy()
+        c1 = np.full(n, episode & MASK, np.uint64)
+        c2 = step.copy()
+        c3 = np.uint64(P_NOISE << 24) | (agent << np.uint64(agent_shift)) | np.uint64(blk_i)
+        k0, k1 = seed & MASK, (seed >> 32) & MASK
+        for _ in range(10):
+            p0, p1 = m0 * c0, m1 * c2
+            c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & msk, p1 & msk, \
+                ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & msk, p0 & msk
+            k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+        f32 = np.float32
+        for pair, (a, b) in enumerate(((c0, c1), (c2, c3))):
+            u1 = ((a >> np.uint64(8)).astype(f32) + f32(0.5)) * f32(1.0 / 16777216.0)
+            u2 = ((b >> np.uint64(8)).astype(f32) + f32(0.5)) * f32(1.0 / 16777216.0)
+            rad = np.sqrt(f32(-2.0) * np.log(u1))
+            ang = f32(6.2831853071795865) * u2
+            out[:, 4 * blk_i + 2 * pair] = rad * np.cos(ang)
+            out[:, 4 * blk_i + 2 * pair + 1] = rad * np.sin(ang)
+    return out[:, :out_dim]
