@@ -252,7 +252,7 @@ def time_env_steps(device, rank, world, B, steps, warmup):
 
     cfg = dict(ENV_CONFIG)
     cfg["disable_env_exploration"] = True
-    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B, latency_log_capacity=0)
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B)
     n = env.n_nodes
     T = env.episode_len
     # pre-generated random actions, resident in HBM: placement ~ U{0..n-1}, resource ~ U(0.1, 1.0)
@@ -313,7 +313,7 @@ def fused_leg(device, rank, world, B, k_steps=250, launches=8):
     from marl_amd.env import BatchedEdgeSimGym
     cfg = dict(ENV_CONFIG)
     cfg["disable_env_exploration"] = True
-    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B, latency_log_capacity=0)
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device=device, seed=0, env_offset=rank * B)
     n, T = env.n_nodes, env.episode_len
     gen = torch.Generator(device=device).manual_seed(4321 + rank)
     pl = torch.randint(0, n, (k_steps, B, n), device=device, generator=gen, dtype=torch.int32)

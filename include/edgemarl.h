@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 4
+#define EM_ABI_VERSION 5
 
 typedef enum em_status {
     EM_OK = 0,
@@ -302,6 +302,21 @@ typedef struct em_rollout {
 
 /* y[rows][out_dim] = MLP(x[rows][ldx]) on the f32 matrix cores (MAPPOActor.forward / MAPPOCritic.forward). */
 int em_mlp3_forward(const em_mlp3 *net, const float *x, int64_t ldx, int64_t n_rows, float *y, void *stream);
+
+/* MAPPOActor.get_action_log_prob given actions (mappo_algorithm.py:50-71): per row, log N(action; mu, exp(log_std)) summed
+ * over the out_dim components and the entropy of that Gaussian summed likewise.  mu/action [n_rows][out_dim], log_std
+ * [out_dim]; either output may be NULL. */
+int em_gauss_logp(const float *mu, const float *log_std, const float *action, int64_t n_rows, int32_t out_dim,
+                  float *logp_out, float *entropy_out, void *stream);
+/* Normal(mu, exp(log_std)).rsample() on pre-drawn standard normals eps [n_rows][out_dim] (mappo_algorithm.py:62-65):
+ * action = mu + eps * exp(log_std). */
+int em_gauss_sample(const float *mu, const float *log_std, const float *eps, int64_t n_rows, int32_t out_dim,
+                    float *action_out, void *stream);
+/* MAPPOTrainer._format_env_actions (mappo_trainer.py:125-158) per row of raw action vectors [n_rows][n_nodes+1]:
+ * placement = 0 when the first n_nodes components are all within 1e-8 of 0, else their first argmax; resource =
+ * float32(0.1 + 0.9 * clip((tanh(x_last) + 1) / 2, 0, 1)), tanh in float64. */
+int em_format_actions(const float *raw_actions, int64_t n_rows, int32_t n_nodes, int32_t *placement_out,
+                      float *resource_out, void *stream);
 
 /* Record which agents act at step t: indexes and compacts the observations of the environment's
  * current obs/active/rank outputs into the rollout buffers (RolloutBuffer.add of obs and state,

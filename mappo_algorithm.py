@@ -1,4 +1,2 @@
 """Drop-in module name of the reference's ``mappo_algorithm.py``; see ``marl_amd/mappo.py``."""
-from marl_amd.mappo import MAPPO, MAPPOActor, MAPPOCritic, RolloutStorage, ValueNormalizer  # noqa: F401
-
-RolloutBuffer = RolloutStorage
+from marl_amd.mappo import MAPPO, MAPPOActor, MAPPOCritic, RolloutBuffer, RolloutStorage, ValueNormalizer  # noqa: F401

@@ -14,7 +14,7 @@ from .config import EmConfig, EmmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class EmTape(C.Structure):
@@ -144,6 +144,12 @@ def lib() -> C.CDLL:
                  "ems_get_state"):
         getattr(L, name).restype = C.c_int
     L.em_mlp3_forward.argtypes = [C.POINTER(EmMlp3), vp, i64, i64, vp, vp]
+    L.em_gauss_logp.argtypes = [vp, vp, vp, i64, C.c_int32, vp, vp, vp]
+    L.em_gauss_logp.restype = C.c_int
+    L.em_gauss_sample.argtypes = [vp, vp, vp, i64, C.c_int32, vp, vp]
+    L.em_gauss_sample.restype = C.c_int
+    L.em_format_actions.argtypes = [vp, i64, C.c_int32, vp, vp, vp]
+    L.em_format_actions.restype = C.c_int
     L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
                                  C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]

@@ -116,6 +116,36 @@ def mean_arrivals_bound(config: dict, margin: float = 1.25) -> float:
     return float(margin * max(mean.max(), 0.05)) + float(first.max()) / max(1, int(config.get("episode_length", 1000)))
 
 
+def latency_log_capacity(config: dict, n_envs: int, per_step_cap: int) -> int:
+    """Per-environment capacity of the latency log behind the exact p99 metric (MRRL.PY:476-479 keeps EVERY latency of
+    the episode).  Small batches get the hard worst case (``per_step_cap`` tasks every step); large ones 1.5x the bound on
+    the mean number of tasks of an episode, rounded up to a power of two (the metrics kernel sorts in LDS): 2,048 doubles =
+    16 KB per environment at the default config, where an episode dispatches ~870 tasks with a standard deviation of ~30.
+    An environment that overflows its log reports NaN for p99 (and only for p99); callers count such environments."""
+    T = int(config.get("episode_length", 1000))
+    full = T * int(per_step_cap)
+    if int(n_envs) <= 1024:
+        return full
+    need = int(1.5 * mean_arrivals_bound(config, margin=1.0) * T) + 64
+    cap = 1
+    while cap < need:
+        cap <<= 1
+    return min(full, cap)
+
+
+def summarise_episode_metrics(metrics, has_final):
+    """Mean of the per-environment episode metrics as MAPPOTrainer.train_episode reports them (mappo_trainer.py:222-250):
+    an environment whose final step produced no observation contributes 0.0 to every key (the reference only harvests
+    ``infos`` of agents present in the last observation).  A metric that is MISSING (NaN: a p99 whose latency log
+    overflowed or was switched off) is never turned into a number: it is left out of the mean and counted.
+    Returns (means [6] float64 on the host, number of environments without an exact p99)."""
+    import torch
+    zero = torch.zeros((), dtype=metrics.dtype, device=metrics.device)
+    per_env = torch.where(has_final.reshape(-1, 1).bool(), metrics, zero)
+    missing = int(torch.isnan(per_env[:, 1]).sum().item())
+    return torch.nanmean(per_env, dim=0).cpu().numpy(), missing
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # EdgeMARLEnv (PyMARL twin environment): env_args of pymarl/src/config/envs/edge_marl.yaml:3-19
 # ---------------------------------------------------------------------------------------------------------------

@@ -502,6 +502,59 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     }
 }
 
+// Normal(mu, exp(log_std)).log_prob(action).sum(-1) and .entropy().sum(-1) per row (mappo_algorithm.py:43-71): one
+// thread per row, components summed in index order in float32 (torch's sum(dim=-1) over <= 16 components is sequential).
+__global__ __launch_bounds__(256) void gauss_logp_kernel(const float* __restrict__ mu, const float* __restrict__ log_std,
+                                                         const float* __restrict__ action, int64_t rows, int O,
+                                                         float* __restrict__ logp, float* __restrict__ entropy)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float lp = 0.0f, en = 0.0f;
+    for (int o = 0; o < O; ++o) {
+        const float ls = log_std[o], sd = expf(ls);
+        const float d = action[r * O + o] - mu[r * O + o];
+        lp += -(d * d) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f;
+        en += 0.5f + 0.91893853320467274f + ls;
+    }
+    if (logp) logp[r] = lp;
+    if (entropy) entropy[r] = en;
+}
+
+// Normal(mu, exp(log_std)).rsample() given the standard-normal draws (mappo_algorithm.py:62-65): a = mu + eps * sigma
+__global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restrict__ mu, const float* __restrict__ log_std,
+                                                           const float* __restrict__ eps, int64_t total, int O,
+                                                           float* __restrict__ action)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float scaled = eps[i] * expf(log_std[i % O]);
+    action[i] = mu[i] + scaled;
+}
+
+// MAPPOTrainer._format_env_actions (mappo_trainer.py:125-158) per row: placement = 0 if every one of the first n
+// components is within 1e-8 of 0 (np.allclose(x, 0) with its default atol), else the first argmax; resource =
+// float32(0.1 + 0.9 * clip((tanh(x_n) + 1) / 2, 0, 1)) with the tanh in float64.
+__global__ __launch_bounds__(256) void format_actions_kernel(const float* __restrict__ raw, int64_t rows, int n,
+                                                             int32_t* __restrict__ placement, float* __restrict__ resource)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* a = raw + r * (n + 1);
+    bool all_zero = true;
+    float best = -__builtin_inff();
+    int best_i = 0;
+    for (int o = 0; o < n; ++o) {
+        const float v = a[o];
+        if (fabsf(v) > 1e-8f) all_zero = false;
+        if (v > best) { best = v; best_i = o; }
+    }
+    double norm = (tanh((double)a[n]) + 1.0) / 2.0;
+    norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
+    placement[r] = all_zero ? 0 : best_i;
+    resource[r] = (float)(0.1 + 0.9 * norm);
+}
+
 int check_net(const em_mlp3* net)
 {
     if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3)
@@ -550,6 +603,40 @@ int em_mlp3_forward(const em_mlp3* net, const float* x, int64_t ldx, int64_t n_r
     std::memset(&fa, 0, sizeof fa);
     fa.net = *net; fa.x = x; fa.ldx = ldx; fa.n_rows = n_rows; fa.y = y;
     return launch_fwd<0>(fa, n_rows, (hipStream_t)stream);
+}
+
+int em_gauss_logp(const float* mu, const float* log_std, const float* action, int64_t n_rows, int32_t out_dim, float* logp_out,
+                  float* entropy_out, void* stream)
+{
+    if (!mu || !log_std || !action || (!logp_out && !entropy_out)) return em::fail(EM_ERR_INVALID, "em_gauss_logp: null argument");
+    if (n_rows < 0 || out_dim < 1 || out_dim > 4096) return em::fail(EM_ERR_INVALID, "em_gauss_logp: bad sizes");
+    if (n_rows == 0) return EM_OK;
+    hipLaunchKernelGGL(gauss_logp_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, log_std,
+                       action, n_rows, (int)out_dim, logp_out, entropy_out);
+    return em::hip_check(hipGetLastError(), "gauss_logp_kernel launch");
+}
+
+int em_gauss_sample(const float* mu, const float* log_std, const float* eps, int64_t n_rows, int32_t out_dim, float* action_out,
+                    void* stream)
+{
+    if (!mu || !log_std || !eps || !action_out) return em::fail(EM_ERR_INVALID, "em_gauss_sample: null argument");
+    if (n_rows < 0 || out_dim < 1 || out_dim > 4096) return em::fail(EM_ERR_INVALID, "em_gauss_sample: bad sizes");
+    if (n_rows == 0) return EM_OK;
+    const int64_t total = n_rows * out_dim;
+    hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, log_std,
+                       eps, total, (int)out_dim, action_out);
+    return em::hip_check(hipGetLastError(), "gauss_sample_kernel launch");
+}
+
+int em_format_actions(const float* raw_actions, int64_t n_rows, int32_t n_nodes, int32_t* placement_out, float* resource_out,
+                      void* stream)
+{
+    if (!raw_actions || !placement_out || !resource_out) return em::fail(EM_ERR_INVALID, "em_format_actions: null argument");
+    if (n_rows < 0 || n_nodes < 1 || n_nodes > 4096) return em::fail(EM_ERR_INVALID, "em_format_actions: bad sizes");
+    if (n_rows == 0) return EM_OK;
+    hipLaunchKernelGGL(format_actions_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw_actions,
+                       n_rows, (int)n_nodes, placement_out, resource_out);
+    return em::hip_check(hipGetLastError(), "format_actions_kernel launch");
 }
 
 int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,

@@ -10,6 +10,7 @@ import torch
 
 from . import _lib
 from .config import ENV_CONFIG, make_em_config
+from .config import latency_log_capacity as default_latency_log_capacity
 
 METRIC_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "violation_rate", "throughput_tps",
                "load_balance_jain")
@@ -66,7 +67,7 @@ class BatchedEdgeSimGym:
         self.cpu_caps = np.asarray(self.config["node_cpu_capacity"], np.float64)
         self._cfg = make_em_config(self.config)
         if latency_log_capacity is None:   # exact p99 needs every latency of the episode (MRRL.PY:476-479)
-            latency_log_capacity = self.episode_len * self.n_nodes if self.n_envs <= 1024 else 0
+            latency_log_capacity = default_latency_log_capacity(self.config, self.n_envs, self.n_nodes)
         self.latency_log_capacity = int(latency_log_capacity)
         self._L = _lib.lib()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from .config import SCALED_ENV_CONFIG, make_em_config
+from .config import latency_log_capacity as default_latency_log_capacity
 from .env import _stream_ptr
 
 PENDING_CAP = 64
@@ -28,7 +29,7 @@ class ScaledEdgeSimGym:
     the list outputs are meaningful.  ``reward`` applies the consumer rule of mappo_trainer.py:209-212."""
 
     def __init__(self, config=None, n_envs: int = 1, device="cuda:0", seed: int = 0, env_offset: int = 0,
-                 latency_log_capacity: int = 0):
+                 latency_log_capacity: int | None = None):
         self.config = dict(SCALED_ENV_CONFIG if config is None else config)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -37,6 +38,8 @@ class ScaledEdgeSimGym:
         self.n_nodes = int(self.config["n_nodes"])
         self.n_deciders = int(self.config.get("n_deciders", self.n_nodes))
         self.episode_len = int(self.config["episode_length"])
+        if latency_log_capacity is None:   # exact p99 needs every latency of the episode (MRRL.PY:476-479)
+            latency_log_capacity = default_latency_log_capacity(self.config, self.n_envs, min(self.n_deciders, PENDING_CAP))
         self.latency_log_capacity = int(latency_log_capacity)
         self._cfg = make_em_config(self.config)
         self._L = _lib.lib()

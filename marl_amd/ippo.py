@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib, gmlp
-from .config import SCALED_ENV_CONFIG, mean_arrivals_bound
+from .config import SCALED_ENV_CONFIG, mean_arrivals_bound, summarise_episode_metrics
 from .env import METRIC_KEYS
 from .env_scaled import PENDING_CAP, ScaledEdgeSimGym
 from .parallel import GradSync
@@ -273,8 +273,7 @@ class IPPOTrainer:
         self.seed, self.n_envs, self.rank, self.world_size = int(seed), int(n_envs), int(rank), int(world_size)
         cfg = dict(SCALED_ENV_CONFIG if env_config is None else env_config)
         self.env_offset = self.rank * self.n_envs
-        self.env = ScaledEdgeSimGym(cfg, n_envs=self.n_envs, device=self.device, seed=self.seed, env_offset=self.env_offset,
-                                    latency_log_capacity=0)
+        self.env = ScaledEdgeSimGym(cfg, n_envs=self.n_envs, device=self.device, seed=self.seed, env_offset=self.env_offset)
         self.S, self.D = self.env.n_nodes, self.env.n_deciders
         self.algorithm = algorithm
         eps_bound = mean_arrivals_bound(cfg)
@@ -339,13 +338,12 @@ class IPPOTrainer:
         if record_buffer:
             total_reward = ro.t["reward_tb"][:T].sum(dim=0)
         metrics = env.episode_metrics()
-        has_final = (env.n_pending > 0).to(torch.float64).unsqueeze(1)      # mappo_trainer.py:222-231
-        per_env = torch.nan_to_num(metrics, nan=0.0) * has_final
-        mean = per_env.mean(dim=0).cpu().numpy()
+        mean, p99_missing = summarise_episode_metrics(metrics, env.n_pending > 0)      # mappo_trainer.py:222-231
         idx = {k: i for i, k in enumerate(METRIC_KEYS)}
         stats = {"episode_reward": float(total_reward.mean().item()), "episode_steps": T}
         for k in _STAT_KEYS:
             stats[k] = float(mean[idx[k]])
+        stats["p99_envs_missing"] = p99_missing
         stats["per_env"] = {"episode_reward": total_reward, "metrics": metrics}
         return stats
 

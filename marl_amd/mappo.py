@@ -71,6 +71,30 @@ class MAPPOActor(_FlatNet):
     def forward(self, obs):
         return mlp3_forward(self.net(), obs)
 
+    def get_action_log_prob(self, obs, action=None):
+        """mappo_algorithm.py:50-71 on device tensors: ``(action, log_prob, entropy)`` with log-prob and entropy summed
+        over the action components.  ``action=None`` samples a = mu + sigma * eps; eps is drawn exactly as
+        ``Normal.rsample()`` draws it on a CPU module (``torch.normal(zeros, ones)`` on torch's global CPU generator), so
+        ``torch.manual_seed`` reproduces the reference's samples."""
+        obs = torch.as_tensor(obs, dtype=torch.float32, device=self.flat.device).reshape(-1, self.obs_dim).contiguous()
+        mu = self.forward(obs)
+        rows, A, dev = mu.shape[0], self.action_dim, mu.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            s = _stream(dev)
+            if action is None:
+                eps = torch.normal(torch.zeros(rows, A), torch.ones(rows, A)).to(dev)
+                action = torch.empty_like(mu)
+                _lib.check(L.em_gauss_sample(mu.data_ptr(), self.log_std.data_ptr(), eps.data_ptr(), rows, A, action.data_ptr(), s),
+                           "em_gauss_sample")
+            else:
+                action = torch.as_tensor(action, dtype=torch.float32, device=dev).reshape(rows, A).contiguous()
+            logp = torch.empty(rows, dtype=torch.float32, device=dev)
+            ent = torch.empty(rows, dtype=torch.float32, device=dev)
+            _lib.check(L.em_gauss_logp(mu.data_ptr(), self.log_std.data_ptr(), action.data_ptr(), rows, A, logp.data_ptr(),
+                                       ent.data_ptr(), s), "em_gauss_logp")
+        return action, logp, ent
+
 
 class MAPPOCritic(_FlatNet):
     """Central critic 140->64->64->1 (mappo_algorithm.py:74-90)."""
@@ -104,6 +128,24 @@ class ValueNormalizer(nn.Module):
         self.register_buffer("running_mean", torch.zeros(input_shape, device=device))
         self.register_buffer("running_var", torch.ones(input_shape, device=device))
         self.register_buffer("count", torch.ones((), device=device))
+
+    def forward(self, x):
+        return (x - self.running_mean) / torch.sqrt(self.running_var + 1e-8)
+
+    def denormalize(self, x):
+        return x * torch.sqrt(self.running_var + 1e-8) + self.running_mean
+
+    def update(self, x):
+        self.update_from_moments(x.mean(dim=0), x.var(dim=0), x.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        """mappo_algorithm.py:396-409 (bookkeeping of three buffers; the kernels read them as scalars)."""
+        delta = batch_mean - self.running_mean
+        tot_count = self.count + batch_count
+        m2 = self.running_var * self.count + batch_var * batch_count + delta ** 2 * self.count * batch_count / tot_count
+        self.running_mean = self.running_mean + delta * batch_count / tot_count
+        self.running_var = m2 / tot_count
+        self.count = tot_count
 
 
 def mlp3_forward(net: _lib.EmMlp3, x: torch.Tensor) -> torch.Tensor:
@@ -166,8 +208,39 @@ class HipAdam:
             self.step_count = int(float(st["step"]))
 
 
+class RolloutBuffer:
+    """The reference's python-list buffer (mappo_algorithm.py:93-131), same members and methods: a host-side container for
+    callers that feed MAPPO one dict transition at a time (``MAPPOTrainer._store_transition``).  ``MAPPO.update()`` uploads
+    it into a one-environment ``RolloutStorage`` and runs the same device kernels as the batched path."""
+
+    def __init__(self):
+        self.clear()
+
+    def add(self, obs, state, action, reward, done, log_prob, value):
+        self.observations.append(obs)
+        self.states.append(state)
+        self.actions.append(action)
+        self.rewards.append(reward)
+        self.dones.append(done)
+        self.log_probs.append(log_prob)
+        self.values.append(value)
+
+    def clear(self):
+        self.observations, self.states, self.actions = [], [], []
+        self.rewards, self.dones, self.log_probs, self.values = [], [], [], []
+
+    def get(self):
+        return {"observations": self.observations, "states": self.states, "actions": self.actions, "rewards": self.rewards,
+                "dones": self.dones, "log_probs": self.log_probs, "values": self.values}
+
+    def __len__(self):
+        return len(self.rewards)
+
+
 class RolloutStorage:
-    """Device buffers of ``em_rollout`` for one batch of episodes (RolloutBuffer, mappo_algorithm.py:93-131)."""
+    """Device buffers of ``em_rollout`` for one batch of episodes (RolloutBuffer, mappo_algorithm.py:93-131).  The
+    reference's ``add/get`` list interface is kept beside it (``staged``): transitions added one at a time are uploaded by
+    ``MAPPO.update()``."""
 
     def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None, entries_per_step=2.2):
         """``entries_per_step``: bound on the MEAN number of acting agents per environment step used to size large
@@ -193,11 +266,55 @@ class RolloutStorage:
         self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() for v in self.t.values()])
         self.ref = C.byref(self.struct)
         self.steps_recorded = 0
+        self.staged = RolloutBuffer()
 
     def clear(self):
         self.t["counters"].zero_()
         self.t["k_tb"].zero_()
         self.steps_recorded = 0
+        self.staged.clear()
+
+    # the reference's list interface (mappo_algorithm.py:104-131)
+    def add(self, obs, state, action, reward, done, log_prob, value):
+        self.staged.add(obs, state, action, reward, done, log_prob, value)
+
+    def get(self):
+        return self.staged.get()
+
+    @classmethod
+    def from_lists(cls, data, n_nodes, device, value_norm=(0.0, 1.0)):
+        """One-environment storage holding a flattened transition list (RolloutBuffer.get()): entry i is its own step
+        (k = 1), so GAE chains through the list exactly as mappo_algorithm.py:250-258 and the critic is evaluated once per
+        entry on that entry's own state, as mappo_algorithm.py:303 does."""
+        import numpy as np
+        L = len(data["rewards"])
+        n = int(n_nodes)
+        st = cls(1, n, L, device, capacity_entries=L, capacity_steps=L)
+        f32 = torch.float32
+        up = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(device)  # noqa: E731
+        t = st.t
+        t["ent_obs"].copy_(up(np.asarray(data["observations"], np.float32).reshape(L, n + 4), f32))
+        t["st_state"].copy_(up(np.asarray(data["states"], np.float32).reshape(L, n * (n + 4)), f32))
+        t["ent_action"].copy_(up(np.asarray(data["actions"], np.float32).reshape(L, n + 1), f32))
+        t["ent_logp"].copy_(up(np.asarray(data["log_probs"], np.float32), f32))
+        vals = up(np.asarray(data["values"], np.float32), f32)
+        t["st_value"].copy_(vals)
+        t["value_tb"].copy_(vals.view(L, 1))
+        t["reward_tb"].copy_(up(np.asarray(data["rewards"], np.float64), torch.float64).view(L, 1))
+        t["done_tb"].copy_(up(np.asarray(data["dones"], np.bool_).astype(np.uint8), torch.uint8).view(L, 1))
+        t["k_tb"].fill_(1)
+        t["st_k"].fill_(1)
+        ar = torch.arange(L, dtype=torch.int32, device=device)
+        t["first_tb"].copy_(ar.view(L, 1))
+        t["st_first"].copy_(ar)
+        c = torch.zeros((L + 1, 4), dtype=torch.int64)
+        c[:, 0] = torch.arange(L + 1)
+        c[:, 2] = torch.arange(L + 1)
+        c[:L, 1] = 1
+        c[:L, 3] = 1
+        t["counters"].copy_(c.to(device))
+        st.steps_recorded = L
+        return st
 
     def totals_raw(self):
         """(entries, steps, error flag) recorded so far, without raising; synchronises."""
@@ -217,7 +334,7 @@ class RolloutStorage:
         return e, s
 
     def __len__(self):
-        return self.totals()[0]
+        return (self.totals()[0] if self.steps_recorded else 0) + len(self.staged)
 
 
 class MAPPO:
@@ -312,13 +429,41 @@ class MAPPO:
         self._nets_cached = (C.byref(self._net_structs[0]), C.byref(self._net_structs[1]), self.actor.log_std.data_ptr())
 
     # -- GAE (mappo_algorithm.py:241-262) --------------------------------------------------------------
-    def compute_gae(self):
+    def compute_gae(self, rewards=None, values=None, dones=None, next_value=0.0):
+        """Without arguments: GAE over the device rollout storage (the batched trainer's path), results in the storage.
+        With the reference's arguments (mappo_algorithm.py:241: flattened lists + ``next_value``): the same ``em_gae``
+        kernel on a one-environment upload of the lists, returns ``(advantages, returns)`` as python lists.  The
+        recursion runs in float64 like the reference's; the kernel stores float32, which is the cast the reference
+        applies to both lists right afterwards (mappo_algorithm.py:289-290)."""
+        if rewards is not None:
+            return self._compute_gae_lists(rewards, values, dones, next_value)
         ro = self.buffer
         self.join_value()
         with torch.cuda.device(self.device):
             _lib.check(self._L.em_gae(C.byref(ro.struct), float(self.gamma), float(self.gae_lambda),
                                       self._gae_partials.data_ptr(), self._gae_partials.numel(), self.moments.data_ptr(),
                                       _stream(self.device)), "em_gae")
+
+    def _compute_gae_lists(self, rewards, values, dones, next_value):
+        import numpy as np
+        L = len(rewards)
+        if L == 0:
+            return [], []
+        r = np.asarray(rewards, np.float64).copy()
+        d = np.asarray(dones, np.bool_)
+        # next_value closes the list: delta_last = r + gamma * next_value * (1 - done) - v (mappo_algorithm.py:251-256);
+        # em_gae closes with 0, so the term is folded into the last reward (same float64 sum, same order)
+        r[-1] = r[-1] + float(self.gamma) * float(next_value) * (1.0 - float(d[-1]))
+        data = {"observations": np.zeros((L, self.obs_dim), np.float32), "states": np.zeros((L, self.state_dim), np.float32),
+                "actions": np.zeros((L, self.action_dim), np.float32), "log_probs": np.zeros(L, np.float32),
+                "rewards": r, "dones": d, "values": np.asarray(values, np.float64)}
+        st = RolloutStorage.from_lists(data, self.n_agents, self.device)
+        part = torch.zeros(3, dtype=torch.float64, device=self.device)
+        mom = torch.zeros(3, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_gae(st.ref, float(self.gamma), float(self.gae_lambda), part.data_ptr(), 3, mom.data_ptr(),
+                                      _stream(self.device)), "em_gae")
+        return st.t["ent_adv"][:L].double().cpu().tolist(), st.t["ent_ret"][:L].double().cpu().tolist()
 
     # -- update (mappo_algorithm.py:264-345) -----------------------------------------------------------
     def _waves(self, rows, per_cu=1):
@@ -328,6 +473,15 @@ class MAPPO:
 
     def update(self):
         ro = self.buffer
+        if len(ro.staged) and ro.steps_recorded == 0:
+            # transitions added through the reference's list interface (buffer.add, mappo_trainer.py:160-175)
+            listed = RolloutStorage.from_lists(ro.staged.get(), self.n_agents, self.device)
+            ro.staged.clear()
+            self.buffer = listed
+            try:
+                return self.update()
+            finally:
+                self.buffer = ro
         # Every decision that would leave before a collective is taken on GLOBAL totals, so all ranks return, raise or
         # go on together: a rank whose shard recorded nothing still joins every all-reduce (with zero gradients), and an
         # overflow on one rank raises on all of them instead of leaving the others waiting in all_reduce.
@@ -401,7 +555,37 @@ class MAPPO:
                                         float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
                                         g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
 
-    # -- dict-API conveniences of the reference (mappo_algorithm.py:189-239), tiny batches ---------------------
+    # -- dict API of the reference (mappo_algorithm.py:189-239), one environment -------------------------------
+    def get_actions(self, observations, explore=True, noise=None):
+        """``{agent_id: obs}`` -> ``({agent_id: action float32[action_dim]}, {agent_id: log_prob float})``
+        (mappo_algorithm.py:189-224).  explore: a = mu + sigma * eps with eps drawn per agent, in dict order, as
+        ``Normal.rsample()`` draws it on the CPU generator (or taken from ``noise`` [agents, action_dim]); eval: a = mu and
+        log-prob 0.0.  The arithmetic runs in the HIP kernels (em_mlp3_forward, em_gauss_sample, em_gauss_logp)."""
+        import numpy as np
+        ids = list(observations.keys())
+        if not ids:
+            return {}, {}
+        x = torch.as_tensor(np.stack([np.asarray(observations[a], np.float32).reshape(-1) for a in ids])).to(self.device)
+        if explore:
+            if noise is None:
+                A = self.action_dim
+                eps = torch.cat([torch.normal(torch.zeros(1, A), torch.ones(1, A)) for _ in ids])
+            else:
+                eps = torch.as_tensor(np.asarray(noise, np.float32)).reshape(len(ids), self.action_dim)
+            mu = self.actor(x)
+            act = torch.empty_like(mu)
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.em_gauss_sample(mu.data_ptr(), self.actor.log_std.data_ptr(), eps.to(self.device).data_ptr(),
+                                                   len(ids), self.action_dim, act.data_ptr(), _stream(self.device)),
+                           "em_gauss_sample")
+                logp = torch.empty(len(ids), dtype=torch.float32, device=self.device)
+                _lib.check(self._L.em_gauss_logp(mu.data_ptr(), self.actor.log_std.data_ptr(), act.data_ptr(), len(ids),
+                                                 self.action_dim, logp.data_ptr(), None, _stream(self.device)), "em_gauss_logp")
+            act, logp = act.cpu().numpy(), logp.cpu().numpy()
+            return {a: act[i] for i, a in enumerate(ids)}, {a: float(logp[i]) for i, a in enumerate(ids)}
+        mu = self.actor(x).cpu().numpy()
+        return {a: mu[i] for i, a in enumerate(ids)}, {a: 0.0 for a in ids}
+
     def get_values(self, state):
         x = torch.as_tensor(state, dtype=torch.float32, device=self.device).reshape(1, -1)
         mean, var = self._norm()

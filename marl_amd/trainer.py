@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-from .config import ENV_CONFIG, mean_arrivals_bound
+from .config import ENV_CONFIG, mean_arrivals_bound, summarise_episode_metrics
 from .env import METRIC_KEYS, BatchedEdgeSimGym
 from .mappo import MAPPO, RolloutStorage
 
@@ -111,13 +111,12 @@ class MAPPOTrainer:
         metrics = env.episode_metrics()                      # [B, 6] on the device
         # the reference harvests the metrics only when the final step produced observations
         # (mappo_trainer.py:222-231), otherwise it reports 0.0 for all of them
-        has_final = (env.active != 0).to(torch.float64).unsqueeze(1)
-        per_env = torch.nan_to_num(metrics, nan=0.0) * has_final
-        mean = per_env.mean(dim=0).cpu().numpy()
+        mean, p99_missing = summarise_episode_metrics(metrics, env.active != 0)
         idx = {k: i for i, k in enumerate(METRIC_KEYS)}
         stats = {"episode_reward": float(total_reward.mean().item()), "episode_steps": T}
         for k in _STAT_KEYS:
             stats[k] = float(mean[idx[k]])
+        stats["p99_envs_missing"] = p99_missing      # environments whose latency log overflowed (their p99 is NaN, not 0)
         stats["per_env"] = {"episode_reward": total_reward, "metrics": metrics}
         if record_buffer:
             # a full storage is reported here, where the episode's statistics are fetched anyway; the error itself is raised by
@@ -128,6 +127,50 @@ class MAPPOTrainer:
                 print("[marl_amd] " + ro.overflow_message(e, s_) + "; this batch is incomplete and update() will raise",
                       file=sys.stderr, flush=True)
         return stats
+
+    # -- the reference's dict-level helpers (mappo_trainer.py:101-175), one environment at a time -----------------------------
+    def obs_dict_to_state(self, obs_dict):
+        """mappo_trainer.py:101-123: agent-major concatenation, zero rows for agents without an observation.  (The batched
+        path never builds this on the host: the dense observation tensor of the step kernel IS this state.)"""
+        state = np.zeros((self.n_agents, self.obs_dim), dtype=np.float32)
+        for i in range(self.n_agents):
+            o = obs_dict.get(f"node_{i}")
+            if o is not None:
+                state[i] = np.asarray(o, np.float32).reshape(-1)
+        return state.reshape(-1)
+
+    def _format_env_actions(self, actions_dict):
+        """mappo_trainer.py:125-158: raw action vectors -> ``{"placement": int, "resource": float32[1]}`` per agent
+        (``em_format_actions``: first argmax unless all logits are ~0, tanh-squashed share in float64)."""
+        from . import _lib
+        ids = list(actions_dict.keys())
+        if not ids:
+            return {}
+        A = self.n_agents + 1
+        raw = np.zeros((len(ids), A), np.float32)
+        for i, a in enumerate(ids):
+            vec = np.asarray(actions_dict[a], np.float32).reshape(-1)
+            if vec.size < A:                       # short vectors are zero-padded; the share is then read from the pad
+                raw[i, :vec.size] = vec
+            else:                                  # the reference reads logits [0, n) and the LAST component
+                raw[i, :self.n_agents], raw[i, self.n_agents] = vec[:self.n_agents], vec[-1]
+        x = torch.as_tensor(raw).to(self.device)
+        pl = torch.empty(len(ids), dtype=torch.int32, device=self.device)
+        rs = torch.empty(len(ids), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().em_format_actions(x.data_ptr(), len(ids), self.n_agents, pl.data_ptr(), rs.data_ptr(),
+                                                    int(torch.cuda.current_stream(self.device).cuda_stream)), "em_format_actions")
+        pl, rs = pl.cpu().numpy(), rs.cpu().numpy()
+        return {a: {"placement": int(pl[i]), "resource": np.array([rs[i]], dtype=np.float32)} for i, a in enumerate(ids)}
+
+    def _store_transition(self, obs_dict, actions_dict, log_probs_dict, state, reward, dones, value):
+        """mappo_trainer.py:160-175: one buffer entry per acting agent, all sharing state/reward/done/value."""
+        done_flag = dones.get("__all__", False)
+        for agent_id, obs in obs_dict.items():
+            if agent_id not in actions_dict or agent_id not in log_probs_dict:
+                continue
+            self.mappo.buffer.add(obs=obs, state=state, action=actions_dict[agent_id], reward=reward, done=done_flag,
+                                  log_prob=log_probs_dict[agent_id], value=value)
 
     def train(self, num_iterations=1000, update_interval=1, eval_interval=10, eval_episodes=10, max_total_steps=5_000_000):
         """mappo_trainer.py:252-316.  ``timestep`` counts environment steps of ONE environment (the reference's

@@ -7,12 +7,10 @@ mounted.  The reference never travels to the GPU box.
 ``MRRL.PY`` has an upper-case suffix (invisible to Linux ``import``) and top-level imports of
 packages that are not installed here (gymnasium, ray, seaborn).  None of them takes part in the
 arithmetic of ``EdgeSimGym`` (they provide a base class and space descriptors), so they are
-replaced by empty stand-in modules before the file is executed with ``SourceFileLoader``.
+replaced by empty stand-in modules before the file's source text is compiled and executed (never its shipped .pyc).
 """
 from __future__ import annotations
 
-import importlib.machinery
-import importlib.util
 import os
 import sys
 import types
@@ -58,18 +56,25 @@ def load_reference():
         _stub("ray.tune")
         _stub("ray.tune.registry", register_env=lambda *a, **k: None)
         _stub("seaborn")
-        if REFERENCE_ROOT not in sys.path:
-            sys.path.insert(0, REFERENCE_ROOT)
-        loader = importlib.machinery.SourceFileLoader("MRRL", os.path.join(REFERENCE_ROOT, "MRRL.PY"))
-        spec = importlib.util.spec_from_loader("MRRL", loader)
-        mod = importlib.util.module_from_spec(spec)
-        sys.modules["MRRL"] = mod
-        loader.exec_module(mod)
-        mod._is_reference = True
-    import mappo_algorithm  # noqa: E402  (resolved from REFERENCE_ROOT)
-    import mappo_trainer  # noqa: E402
+        _exec_source("MRRL", "MRRL.PY")._is_reference = True
+    # the reference's own modules are executed from their SOURCE TEXT only (compile + exec): the tree also ships
+    # __pycache__/*.cpython-310.pyc files, and a path-based import would run that prebuilt bytecode whenever its header
+    # happened to match the source's mtime/size.  The reference root is never put on sys.path.
+    for name in ("mappo_algorithm", "mappo_trainer"):
+        if not getattr(sys.modules.get(name), "_is_reference", False):
+            _exec_source(name, name + ".py")._is_reference = True
+    return sys.modules["MRRL"], sys.modules["mappo_algorithm"], sys.modules["mappo_trainer"]
 
-    return sys.modules["MRRL"], mappo_algorithm, mappo_trainer
+
+def _exec_source(name: str, filename: str) -> types.ModuleType:
+    path = os.path.join(REFERENCE_ROOT, filename)
+    with open(path, "r", encoding="utf-8") as f:
+        code = compile(f.read(), path, "exec")
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod          # `from MRRL import ...` / `from mappo_algorithm import MAPPO` resolve through here
+    exec(code, mod.__dict__)
+    return mod
 
 
 class RecordingRandom:

@@ -81,3 +81,17 @@ def test_smoke_script_call_surface():
     ev = trainer.evaluate(num_episodes=2)
     assert set(ev) == {"avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tps", "load_balance_jain"}
     assert MRRL.MAPPO_AVAILABLE and callable(MRRL.run_greedy_baseline)
+
+
+def test_trainer_reports_exact_p99_at_4096_envs():
+    """MAPPOTrainer at 4,096 environments: p99_latency_ms comes from the per-environment latency logs (no environment
+    without one) and is the mean of the environments' exact percentiles, not 0.0."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(dict(ENV_CONFIG, episode_length=300), seed=2, device="cuda:0", n_envs=4096, verbose=False)
+    st = tr.train_episode(explore=True, record_buffer=True)
+    assert st["p99_envs_missing"] == 0 and st["p99_latency_ms"] > st["avg_latency_ms"] > 0
+    import torch
+    assert not bool(torch.isnan(st["per_env"]["metrics"]).any())
+    ev = tr.evaluate(num_episodes=4096)
+    assert ev["p99_latency_ms"] > ev["avg_latency_ms"] > 0

@@ -392,3 +392,52 @@ def test_step_many_equals_single_steps(mode, lanes):
     assert torch.equal(one.episode_metrics(), many.episode_metrics())
     with pytest.raises(RuntimeError):
         many.step_many(1, greedy_share=0.5)       # the episode is over
+
+
+def test_exact_p99_at_4096_envs_with_the_default_latency_log():
+    """BASELINE configs[1]'s batch, a full 1000-step episode, the DEFAULT latency log (bounded per-environment capacity
+    above 1,024 environments): the six episode metrics of MRRL.PY:470-504, p99 = np.percentile(latencies * 1000, 99)
+    included, equal the C restatement's for every environment (p99, violation rate, throughput bit for bit)."""
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = eo.default_config()
+    cfg.update(disable_env_exploration=True)
+    B, n, T = 4096, 10, int(cfg["episode_length"])
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=77)
+    assert 0 < env.latency_log_capacity < T * n          # bounded, not the 80 KB-per-environment worst case
+    ref = c_oracle.COracleEnv(cfg, B, seed=77, env_offset=0)
+    ref.set_explore(True, 0)
+    ref.next_episode()
+    ref.reset()
+    env.reset()
+    rs = np.random.RandomState(5)
+    for t in range(T):
+        pl = rs.randint(0, n, size=(B, n)).astype(np.int32)
+        rsrc = rs.uniform(0.1, 1.0, size=(B, n)).astype(np.float32)
+        ref.step(pl, rsrc)
+        env.step(torch.as_tensor(pl).cuda(), torch.as_tensor(rsrc).cuda())
+    m, rm = env.episode_metrics().cpu().numpy(), ref.metrics()
+    assert not np.isnan(m).any()
+    assert np.array_equal(m[:, [1, 3, 4]], rm[:, [1, 3, 4]])
+    np.testing.assert_allclose(m, rm, rtol=1e-12, atol=0)
+    tasks = env.get_state()["counts"][:, 0]
+    assert tasks.max() < env.latency_log_capacity and tasks.min() > 500
+
+
+def test_overflowing_latency_log_reports_nan_never_zero():
+    """An environment whose log is too small reports NaN for p99 (and only p99); the trainer-level summary leaves such
+    environments out of the mean and counts them instead of reporting 0.0."""
+    from marl_amd.config import summarise_episode_metrics
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = eo.default_config()
+    cfg.update(episode_length=80, disable_env_exploration=True)
+    B, n = 64, 10
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=3, latency_log_capacity=16)
+    env.reset()
+    pl = torch.zeros((B, n), dtype=torch.int32, device="cuda")
+    rsrc = torch.full((B, n), 0.5, device="cuda")
+    for _ in range(80):
+        env.step(pl, rsrc)
+    m = env.episode_metrics()
+    assert bool(torch.isnan(m[:, 1]).all()) and not bool(torch.isnan(m[:, [0, 2, 3, 4, 5]]).any())
+    mean, missing = summarise_episode_metrics(m, torch.ones(B, dtype=torch.bool, device="cuda"))
+    assert missing == B and np.isnan(mean[1]) and mean[0] > 0

@@ -78,3 +78,17 @@ def test_update_matches_reference():
     np.testing.assert_allclose(np.mean(np.array(losses4), axis=0), g["loss4"], rtol=1e-6, atol=1e-9)
     for k, v in g["p4"].items():
         np.testing.assert_allclose(p4[k], v, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_restatement_on_a_shipped_reference_checkpoint():
+    """The torch-CPU restatement reproduces what the imported reference networks computed from the reference's own trained
+    checkpoint (tests/golden/ckpt_seed0.npz, written by oracle/make_golden_ckpt.py from mappo_seed_0.pt)."""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "ckpt_seed0.npz"), allow_pickle=False)
+    p = mo.to_torch({k: g[k] for k in g.files if k.startswith(("actor.", "critic."))})
+    mu = mo.actor_mu(p, torch.as_tensor(g["obs"]))
+    np.testing.assert_allclose(mu.numpy(), g["mu"], rtol=1e-6, atol=1e-5)
+    lp, ent = mo.gaussian_logp_entropy(mu, p["actor.log_std"], torch.as_tensor(g["actions"]))
+    np.testing.assert_allclose(lp.numpy(), g["logp"], rtol=1e-6)
+    np.testing.assert_allclose(ent.numpy(), g["entropy"], rtol=1e-6)
+    np.testing.assert_allclose(mo.critic_v(p, torch.as_tensor(g["states"])).numpy(), g["values"], rtol=1e-6)
+    assert float(g["adam_step"]) == 20000.0 and g["norm"].tolist() == [0.0, 1.0, 1.0]
