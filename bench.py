@@ -107,6 +107,15 @@ def cpu_baseline(seconds_target: float = 12.0) -> dict:
     except Exception as e:  # pragma: no cover - informational only
         out["whole_host_error"] = repr(e)
     out["host"] = {"nproc": os.cpu_count(), "cpu": _cpu_model()}
+    # how representative the port is: the imported reference and the port timed side by side in the build container
+    # (oracle/time_vs_reference.py; the reference cannot travel to this box).  ratio > 1: the port is FASTER than the reference
+    try:
+        pv = json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+        out["port_vs_reference"] = {k: {"ratio": v["ratio"], "reference": v["reference"], "port": v["port"], "unit": v["unit"]}
+                                    for k, v in pv.items() if isinstance(v, dict) and "ratio" in v}
+        out["port_vs_reference"]["measured"] = "build container, 8 cores, oracle/time_vs_reference.py"
+    except Exception as e:  # pragma: no cover - informational only
+        out["port_vs_reference"] = {"error": repr(e)}
     return out
 
 
