@@ -86,6 +86,10 @@ typedef struct em_step_out {
     int32_t *n_draws;      /* [n_envs] random draws the reference would have consumed this call */
     double *reward_seen;   /* [n_envs] reward as the trainer sees it: 0 when not emitted
                               (mappo_trainer.py:209-212) */
+    uint64_t *chunk_totals; /* [ceil(n_envs/256)] optional: the kernel ADDS, per chunk of 256 environments, the number of
+                              agents holding a task after the call (low 32 bits) and of environments with at least one
+                              (high 32 bits); zeroed by the caller (or by em_rollout_index_totals).  Not filled by
+                              em_step_many.  Feeds em_rollout_index_totals. */
 } em_step_out;
 
 /* EdgeSimGym.__init__ (MRRL.PY:124-186) for n_envs environments on HIP device `device_id`.
@@ -298,6 +302,13 @@ typedef struct em_rollout {
     int64_t *scan_scratch; /* [ceil(B/256)] scratch of em_rollout_index                           */
     int64_t *counters;     /* [T+1][4] {entry_base, n_entries, step_base, n_steps}; row 0 zeroed by the caller */
     int32_t *err_flag;     /* [1] sticky error bits (8 = capacity overflow), zeroed by the caller */
+    /* States BY REFERENCE (st_state == NULL): the rollout keeps the dense observation tensors of its steps,
+     * obs_tb [slices][n_envs][n_nodes][n_nodes+4] (the step kernel writes each step's observations straight into the
+     * next slice), and a state is the row number of its environment's block there; nothing but the acting agents' rows
+     * is copied when a step is recorded.  With st_state != NULL the state rows are copied (compact) and these two
+     * fields are ignored. */
+    const float *obs_tb;   /* base of the observation history, or NULL                                   */
+    int32_t *st_row;       /* [S]  slice * n_envs + env of the state's block in obs_tb                    */
 } em_rollout;
 
 /* y[rows][out_dim] = MLP(x[rows][ldx]) on the f32 matrix cores (MAPPOActor.forward / MAPPOCritic.forward). */
@@ -323,6 +334,14 @@ int em_format_actions(const float *raw_actions, int64_t n_rows, int32_t n_nodes,
  * mappo_trainer.py:160-175). */
 int em_rollout_index(const em_rollout *ro, int32_t t, const uint64_t *active, const int8_t *rank, const float *obs,
                      void *stream);
+
+/* em_rollout_index for a caller that already holds the per-256-environment totals of the step's acting agents
+ * (em_step_out.chunk_totals: the reset/step kernel counts them while it writes the observations), which saves the
+ * counting launch.  chunk_totals [ceil(n_envs/256)]: low 32 bits = acting agents, high 32 bits = environments with at
+ * least one; chunk_totals_next (optional) is cleared for the next step's kernel to add into (two buffers used
+ * alternately).  No counterpart in the reference. */
+int em_rollout_index_totals(const em_rollout *ro, int32_t t, const uint64_t *active, const int8_t *rank, const float *obs,
+                            const uint64_t *chunk_totals, uint64_t *chunk_totals_next, void *stream);
 
 /* MAPPO.get_actions + MAPPOTrainer._format_env_actions + MAPPO.get_values for step t
  * (mappo_algorithm.py:189-239, mappo_trainer.py:125-158): samples a = mu + sigma*eps for every entry
@@ -382,6 +401,13 @@ int em_ppo_critic_grad(const em_mlp3 *critic, const float *st_state, const int32
                        const float *ent_ret, int64_t n_steps, int64_t n_global, float value_loss_coeff,
                        float value_norm_mean, float value_norm_var, float *slab, int64_t n_waves, float *grad_out,
                        float *loss3_out, void *stream);
+
+/* em_ppo_critic_grad with the states held BY REFERENCE (em_rollout.obs_tb / st_row): state s is the n_nodes*(n_nodes+4)
+ * floats at state_base + st_row[s] * in_dim; st_row == NULL reads state s at row s (= em_ppo_critic_grad). */
+int em_ppo_critic_grad_rows(const em_mlp3 *critic, const float *state_base, const int32_t *st_row, const int32_t *st_first,
+                            const uint8_t *st_k, const float *ent_ret, int64_t n_steps, int64_t n_global,
+                            float value_loss_coeff, float value_norm_mean, float value_norm_var, float *slab,
+                            int64_t n_waves, float *grad_out, float *loss3_out, void *stream);
 
 /* clip_grad_norm_ on each network separately (mappo_algorithm.py:328-329) then torch.optim.Adam's
  * update (:331-332) on flat float32 parameter/moment buffers; step counts from 1.

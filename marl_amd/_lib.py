@@ -33,7 +33,7 @@ class EmStepOut(C.Structure):
     _fields_ = [
         ("obs", C.c_void_p), ("active", C.c_void_p), ("rank", C.c_void_p), ("reward", C.c_void_p),
         ("emitted", C.c_void_p), ("done", C.c_void_p), ("step_latency", C.c_void_p), ("n_draws", C.c_void_p),
-        ("reward_seen", C.c_void_p),
+        ("reward_seen", C.c_void_p), ("chunk_totals", C.c_void_p),
     ]
 
 
@@ -62,7 +62,8 @@ class EmRollout(C.Structure):
         (name, C.c_void_p) for name in (
             "ent_obs", "ent_action", "ent_logp", "ent_env", "ent_agent", "ent_adv", "ent_ret",
             "st_state", "st_value", "st_env", "st_first", "st_k",
-            "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "scan_scratch", "counters", "err_flag")]
+            "reward_tb", "done_tb", "value_tb", "k_tb", "first_tb", "srow", "scan_scratch", "counters", "err_flag",
+            "obs_tb", "st_row")]
 
 
 class EmsRollout(C.Structure):
@@ -151,6 +152,8 @@ def lib() -> C.CDLL:
     L.em_format_actions.argtypes = [vp, i64, C.c_int32, vp, vp, vp]
     L.em_format_actions.restype = C.c_int
     L.em_rollout_index.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp]
+    L.em_rollout_index_totals.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.em_rollout_index_totals.restype = C.c_int
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
                                  C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.em_value_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
@@ -163,6 +166,8 @@ def lib() -> C.CDLL:
     L.em_ppo_slab_floats.restype = i64
     L.em_ppo_actor_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp, i64, vp, vp, vp]
     L.em_ppo_critic_grad.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, i64, i64, f32, f32, f32, vp, i64, vp, vp, vp]
+    L.em_ppo_critic_grad_rows.argtypes = [C.POINTER(EmMlp3), vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, vp, i64, vp, vp, vp]
+    L.em_ppo_critic_grad_rows.restype = C.c_int
     L.em_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, vp, vp, vp, vp, i64, f64, i64, f64, f64, f64, f64, vp, vp]
     G = C.POINTER(EmGmlp)
     L.em_gmlp_forward.argtypes = [G, vp, i64, i64, vp, vp, C.c_int32, vp, vp]

@@ -133,6 +133,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
     double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [64] window per environment
     int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
+    // acting-agent totals of the workgroup's environments per 256-environment chunk (out.chunk_totals): two chunks at
+    // most (a workgroup holds <= 64 environments), then a count of the worker wavefronts that have added theirs
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(s_nnew + 64);   // [2]
+    unsigned int* s_arrived = reinterpret_cast<unsigned int*>(s_tot + 2);             // [1] (+ pad)
 
     // worker coordinates (meaningless on the scalar wavefront)
     const int g_raw = lane / GW, sl = lane - g_raw * GW;
@@ -252,6 +256,8 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
         s_win[lane] = window;
         s_nnew[lane] = n_new;
+        if (lane < 2) s_tot[lane] = 0ull;
+        if (lane == 2) *s_arrived = 0u;
         STAMP(14);
     } else {
         // =========================== worker wavefront, part 1: placements ================================
@@ -610,6 +616,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     }
     const int rank_out = agent ? (int)r_rank[sl] : -1;
     const uint64_t act_bits = group_bits<LPE>(__ballot(rank_out >= 0), g, GW);
+    if (out.chunk_totals && valid && sl == 0 && n_pending > 0) {
+        // {acting agents | environments with at least one << 32} of the next step, per chunk of 256 environments
+        atomicAdd(&s_tot[(env >> 8) != (env_b0 >> 8) ? 1 : 0], (unsigned long long)n_pending | (1ull << 32));
+    }
     if (out.n_draws) {
         int d = draws_lane;
         if constexpr (LPE == 0) {
@@ -656,6 +666,17 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             for (int i = (nfl & ~3) + lane; i < nfl; i += 64) gobs[i] = s_obs_w[i];
         } else {
             for (int i = lane; i < nfl; i += 64) gobs[i] = s_obs_w[i];
+        }
+    }
+    if (out.chunk_totals) {
+        // the worker wavefront that arrives last adds the workgroup's sums to the global totals: two atomics per workgroup
+        // (the LDS adds above were ordered before the fence/wave barrier that precedes the stage-out)
+        unsigned int before = 0u;
+        if (lane == 0) before = atomicAdd(s_arrived, 1u);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before == (unsigned int)(n_work - 1) && lane < 2) {
+            const unsigned long long v = s_tot[lane];
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(out.chunk_totals) + (env_b0 >> 8) + lane, v);
         }
     }
     STAMP(11);
@@ -1427,7 +1448,7 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     const int64_t epb = (int64_t)n_work * epw;           // environments per workgroup
     const int64_t blocks = (h->n_envs + epb - 1) / epb;
     // + the scalar wavefront's window/arrival-count buffers (two-deep in the several-steps kernel)
-    const size_t lds = (size_t)p.wave_bytes * n_work + (k_steps > 1 ? 2 : 1) * 64 * 12;
+    const size_t lds = (size_t)p.wave_bytes * n_work + (k_steps > 1 ? 2 : 1) * 64 * 12 + 32;   // + chunk totals, arrival count
     if (lds > 160 * 1024) return em::fail(EM_ERR_INVALID, "n_nodes too large for the LDS tile (%zu bytes)", lds);
     em_tape tp;
     std::memset(&tp, 0, sizeof tp);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
     }
     // loss sums in float64 per lane: a float32 accumulator that adds one row's (nearly constant) entropy a few thousand times
     // rounds the same way every time and drifted 2e-5 relative at 54 M transitions (tests/test_fullsize_gpu.py)
-    double loss_sum = 0.0, aux_sum = 0.0;
+    double loss_sum = 0.0;
     float cnt_sum = 0.0f;
 
     // the group's own batch statistics: PPO normalises advantages over the learner's batch (mappo_algorithm.py:293)
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 // d min(s1,s2)/d ratio with autograd's tie rule (equal inputs share the gradient)
                 const float wgt = su1 < su2 ? 1.0f : (su1 == su2 ? 0.5f + 0.5f * in_range : in_range);
                 g_lp = -(A * ratio * wgt) * inv_L;                          // d(-mean(min))/d logp
-                if (q == 0) { loss_sum += (double)fminf(su1, su2); cnt_sum += 1.0f; aux_sum += (double)ent_row; }
+                if (q == 0) { loss_sum += (double)fminf(su1, su2); cnt_sum += 1.0f; }
             }
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
@@ -709,7 +709,6 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         loss_sum += __shfl_xor(loss_sum, m);
-        aux_sum += __shfl_xor(aux_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
     out[o_b1 + lane] = gb1_l;
@@ -724,7 +723,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     if constexpr (ACTOR) out[o_ls + 16 * ot + 4 * q + r] = gls[ot][r];
                 }
     }
-    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)aux_sum; out[o_loss + 2] = cnt_sum; }
+    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)((double)ent_row * (double)cnt_sum);   /* the entropy is the same for every row of a group */ out[o_loss + 2] = cnt_sum; }
 }
 
 // grads[g][p] = sum over the group's slab rows, fixed order; the last 3 columns (loss sums) go to loss3[g]

@@ -106,6 +106,7 @@ static std::atomic<double*> g_gae_scratch_ptr[GAE_MAX_DEVICES];
 struct BwdArgs {
     em_mlp3 net;
     const float* x;            // [rows][ldx]
+    const int32_t* x_rows;     // optional: input row r is x[x_rows[r]] (states held by reference in the observation history)
     int64_t ldx, n_rows;
     float* slab;               // [n_waves][slab_stride]
     int64_t slab_stride;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     gb3 = zero4; gls = zero4;
     // loss sums in float64 per lane: a float32 accumulator that adds one row's (nearly constant) entropy a few thousand times
     // rounds the same way every time and drifted 2e-5 relative at 54 M transitions (tests/test_fullsize_gpu.py)
-    double loss_sum = 0.0, aux_sum = 0.0;
+    double loss_sum = 0.0;
     float cnt_sum = 0.0f;
 
     float adv_mean = 0.0f, adv_den = 1.0f, sd[4] = {1.f, 1.f, 1.f, 1.f}, ls[4] = {0.f, 0.f, 0.f, 0.f};
@@ -208,7 +209,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
         const int64_t row_ = tile_ * 16 + c;
         const bool valid_ = row_ < a.n_rows;
-        const float* xr = a.x + (valid_ ? row_ : 0) * a.ldx;
+        int64_t src_ = valid_ ? row_ : 0;
+        if (a.x_rows) src_ = valid_ ? (int64_t)a.x_rows[src_] : 0;
+        const float* xr = a.x + src_ * a.ldx;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = 16 * u + 4 * q;
@@ -241,15 +244,31 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     // "asynchronous" copy then cost a full HBM round trip at the top of every tile (3.7 k of a tile's 27 k cycles by
     // in-kernel cycle stamps).  Here the kernel waits for it itself, at the end of the tile (s_waitcnt(0) below).  M0 = LDS
     // byte address of the 1 KB slice (wave-uniform), lane l lands at M0 + 16 l.
-    auto stage = [&](int64_t tile_, float* dst) {
+    // By reference (a.x_rows): the 16 rows of a tile are scattered; lanes 0..15 hold their row numbers (rows16, fetched two
+    // tiles ahead by tile_rows) and hand them to the copying lanes by shuffle: float4 number idx of the packed [16][K1] tile
+    // comes from row idx / (K1/4), a multiply-high with kv_magic.
+    const int kv = K1 >> 2;
+    const uint32_t kv_magic = (uint32_t)((0x100000000ull + (uint32_t)(kv > 0 ? kv : 1) - 1u) / (uint32_t)(kv > 0 ? kv : 1));
+    auto tile_rows = [&](int64_t tile_) {
+        int v = 0;
+        const int64_t r_ = tile_ * 16 + c;
+        if (a.x_rows && q == 0 && tile_ < n_tiles && r_ < a.n_rows) v = a.x_rows[r_];
+        return v;
+    };
+    auto stage = [&](int64_t tile_, float* dst, int rows16) {
         const float* gt = a.x + tile_ * 16 * (int64_t)K1;
         const int64_t rows_left = a.n_rows - tile_ * 16;
-        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * (K1 >> 2);
+        const int nvv = (int)(rows_left < 16 ? rows_left : 16) * kv;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(dst);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int idx = lane + 64 * j;
-            const float* src = gt + 4 * (idx < nvv ? idx : 0);
+            const int idv = idx < nvv ? idx : 0;
+            const float* src = gt + 4 * idv;
+            if (a.x_rows) {
+                const int rr = (int)__umulhi((uint32_t)idv, kv_magic);
+                src = a.x + (int64_t)__shfl(rows16, rr) * K1 + 4 * (idv - rr * kv);
+            }
             const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 1024u * (unsigned)j);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory", "m0");
         }
@@ -265,9 +284,11 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         if (r0 < a.n_rows && q == 0) { n_k = a.st_k[r0]; n_first = a.st_first[r0]; }
     }
     int cur = 0;
+    int rows_next = 0;                                    // row numbers of the tile that the NEXT iteration stages
     if constexpr (STAGE) {
         const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
-        if (t0 < n_tiles) stage(t0, xs);
+        if (t0 < n_tiles) stage(t0, xs, tile_rows(t0));
+        rows_next = tile_rows(t0 + tile_stride);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -277,7 +298,8 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         const bool valid = row < a.n_rows;
         const float* xt = xs + cur * XBUF;            // STAGE: this tile, [16][K1] packed
         if constexpr (STAGE) {
-            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF);
+            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF, rows_next);
+            rows_next = tile_rows(tile + 2 * tile_stride);
         } else if constexpr (!PREFETCH) load_x(tile, xb);
         // loss inputs of this tile: issued now, needed after the forward pass
         float p_act[4] = {0.f, 0.f, 0.f, 0.f}, p_adv = 0.0f, p_old = 0.0f;
@@ -467,7 +489,6 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     gls[r] += g_lp * (d[r] * d[r] * iv - 1.0f) - a.ecoef * a.inv_L;   // d logp / d log_std ; entropy bonus
                 }
             }
-            if (valid && q == 0) aux_sum += (double)ent_row;
         } else {
             if (valid && q == 0) {
                 const float v = y[0];
@@ -646,7 +667,6 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         loss_sum += __shfl_xor(loss_sum, m);
-        aux_sum += __shfl_xor(aux_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
     out[o_b1 + lane] = gb1_l;
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                 if constexpr (ACTOR) out[o_ls + 4 * q + r] = gls[r];
             }
     }
-    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)aux_sum; out[o_loss + 2] = cnt_sum; }
+    if (lane == 0) { out[o_loss] = (float)loss_sum; out[o_loss + 1] = (float)((double)ent_row * (double)cnt_sum);   /* the entropy is the same for every row */ out[o_loss + 2] = cnt_sum; }
 }
 
 // grads[p] = sum over slab rows in a fixed order (bitwise reproducible): a workgroup owns 32 columns; its 8 row groups sum
@@ -854,14 +874,23 @@ int em_ppo_critic_grad(const em_mlp3* critic, const float* st_state, const int32
                        float value_norm_mean, float value_norm_var, float* slab, int64_t n_waves, float* grad_out,
                        float* loss3_out, void* stream)
 {
+    return em_ppo_critic_grad_rows(critic, st_state, nullptr, st_first, st_k, ent_ret, n_steps, n_global, value_loss_coeff,
+                                   value_norm_mean, value_norm_var, slab, n_waves, grad_out, loss3_out, stream);
+}
+
+int em_ppo_critic_grad_rows(const em_mlp3* critic, const float* state_base, const int32_t* st_row, const int32_t* st_first,
+                            const uint8_t* st_k, const float* ent_ret, int64_t n_steps, int64_t n_global,
+                            float value_loss_coeff, float value_norm_mean, float value_norm_var, float* slab, int64_t n_waves,
+                            float* grad_out, float* loss3_out, void* stream)
+{
     int rc = check_net(critic);
     if (rc) return rc;
-    if (!st_state || !st_first || !st_k || !ent_ret || !slab || !grad_out || !loss3_out)
+    if (!state_base || !st_first || !st_k || !ent_ret || !slab || !grad_out || !loss3_out)
         return em::fail(EM_ERR_INVALID, "em_ppo_critic_grad: null argument");
     if (n_steps < 1 || n_global < 1 || n_waves < 4 || (n_waves & 3)) return em::fail(EM_ERR_INVALID, "em_ppo_critic_grad: bad sizes");
     BwdArgs ba;
     std::memset(&ba, 0, sizeof ba);
-    ba.net = *critic; ba.x = st_state; ba.ldx = critic->in_dim; ba.n_rows = n_steps; ba.slab = slab;
+    ba.net = *critic; ba.x = state_base; ba.x_rows = st_row; ba.ldx = critic->in_dim; ba.n_rows = n_steps; ba.slab = slab;
     ba.slab_stride = em_ppo_slab_floats(critic->in_dim, critic->out_dim, 0);
     ba.inv_L = 1.0f / (float)n_global;
     ba.st_first = st_first; ba.st_k = st_k; ba.ent_ret = ent_ret;

@@ -30,6 +30,7 @@ constexpr int HID = 64;   // hidden width of both networks (mappo_algorithm.py:2
 struct FwdArgs {
     em_mlp3 net;
     const float* x;            // [rows][ldx]
+    const int32_t* x_rows;     // optional: row r of the launch reads x[x_rows[row_base + r]] (states held by reference)
     int64_t ldx;
     int64_t n_rows;            // used when dyn == nullptr
     const int64_t* dyn;        // optional {row_base, n_rows} in device memory
@@ -95,7 +96,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
     auto load_x = [&](int64_t tile_, float(&xb_)[KU * 4]) {
         const int64_t row_ = tile_ * 16 + c;
         const bool valid_ = row_ < n_rows;
-        const float* xr = a.x + (row_base + (valid_ ? row_ : 0)) * a.ldx;
+        int64_t src_ = row_base + (valid_ ? row_ : 0);
+        if (a.x_rows) src_ = valid_ ? (int64_t)a.x_rows[src_] : 0;
+        const float* xr = a.x + src_ * a.ldx;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = 16 * u + 4 * q;
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     int64_t* __restrict__ counters, uint8_t* __restrict__ k_tb, int32_t* __restrict__ first_tb, int32_t* __restrict__ srow,
     int64_t cap_e, int64_t cap_s, int32_t* __restrict__ err, float* __restrict__ ent_obs, int32_t* __restrict__ ent_env,
     int8_t* __restrict__ ent_agent, float* __restrict__ st_state, int32_t* __restrict__ st_env,
-    int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k)
+    int32_t* __restrict__ st_first, uint8_t* __restrict__ st_k, int32_t* __restrict__ st_row, int64_t row_base,
+    unsigned long long* __restrict__ zero_next)
 {
     __shared__ unsigned long long red[2][CHUNK / 64];
     __shared__ unsigned long long wave_tot[CHUNK / 64];
@@ -355,7 +359,13 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     __shared__ uint16_t s_list[CHUNK];
     __shared__ uint8_t s_k[CHUNK];
     __shared__ int8_t s_rank[CHUNK * 64];       // arrival ranks of the chunk (n <= 64)
+    __shared__ uint16_t s_src[CHUNK * 64];      // by-reference mode: chunk-local observation row (env * n + agent) of each entry
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // totals of the NEXT step's parity buffer: written by the environment kernel of the next step, so they are cleared
+    // here, by the only kernel that runs between their last reader (the previous index launch) and that writer
+    if (zero_next) {
+        for (int i = (int)blockIdx.x * CHUNK + tid; i < n_chunks; i += (int)gridDim.x * CHUNK) zero_next[i] = 0ull;
+    }
     const int64_t e_base = counters[4 * t + 0], s_base = counters[4 * t + 2];
     // the chunk's arrival ranks depend on nothing: requested first (held in registers until the LDS tile is free to take
     // them), so their round trip runs beside the scan instead of after it
@@ -440,6 +450,52 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     }
     __syncthreads();
     const uint32_t magic_w = (uint32_t)((0x100000000ull + (uint32_t)w - 1u) / (uint32_t)w);   // e / w for e < 2^16
+    if (!st_state) {
+        // ---- states held BY REFERENCE: the dense observation tensor of this step stays where the environment kernel
+        // wrote it (a slice of the rollout's observation history) and a state is its row number there; only the acting
+        // agents' rows (56 B each at n = 10) are copied, entry-parallel.
+        const int64_t f0 = e_base + (int64_t)(pre & 0xffffffffull);          // first entry of the chunk
+        const int n_ent = (int)(ctot & 0xffffffffull);
+        for (int e = tid; e < CHUNK * n; e += CHUNK) {
+            const int i = (int)__umulhi((uint32_t)e, (uint32_t)((0x100000000ull + (uint32_t)n - 1u) / (uint32_t)n)), ag = e - i * n;
+            const int r = s_rank[e];
+            if (r >= 0 && s_k[i]) {
+                const int64_t f = s_first[i];
+                s_src[(int)(f - f0) + r] = (uint16_t)e;
+                ent_env[f + r] = (int32_t)(cb + i);
+                ent_agent[f + r] = (int8_t)ag;
+            }
+        }
+        __syncthreads();
+        const int total = n_ent * w;
+        const float* src0 = obs + cb * sw;
+        float* dst0 = ent_obs + f0 * w;
+        constexpr int U = 4;
+        for (int e0 = tid; e0 < total; e0 += CHUNK * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * CHUNK;
+                if (e < total) {
+                    const int j = (int)__umulhi((uint32_t)e, magic_w), col = e - j * w;
+                    x[u] = src0[(int)s_src[j] * w + col];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * CHUNK;
+                if (e < total) dst0[e] = x[u];
+            }
+        }
+        for (int j = tid; j < n_loc; j += CHUNK) {
+            const int i = s_list[j];
+            st_env[sr0 + j] = (int32_t)(cb + i);
+            st_first[sr0 + j] = s_first[i];
+            st_k[sr0 + j] = s_k[i];
+            st_row[sr0 + j] = (int32_t)(row_base + cb + i);
+        }
+        return;
+    }
     if ((sw & 3) == 0) {   // rows are 16-byte multiples (obs and st_state bases are 16-byte aligned by contract)
         const int v4 = sw >> 2, total = n_loc * v4;
         const uint32_t magic_v = (uint32_t)((0x100000000ull + (uint32_t)v4 - 1u) / (uint32_t)v4);
@@ -639,25 +695,58 @@ int em_format_actions(const float* raw_actions, int64_t n_rows, int32_t n_nodes,
     return em::hip_check(hipGetLastError(), "format_actions_kernel launch");
 }
 
-int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
-                     void* stream)
+}  // extern "C"
+
+namespace {
+int rollout_index_impl(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
+                       const uint64_t* chunk_totals, uint64_t* chunk_totals_next, void* stream)
 {
     if (!ro || !active || !rank || !obs) return em::fail(EM_ERR_INVALID, "em_rollout_index: null argument");
     if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_rollout_index: step %d outside [0,%d)", t, ro->horizon);
-    if (!ro->scan_scratch) return em::fail(EM_ERR_INVALID, "em_rollout_index: scan_scratch is required");
+    if (!ro->scan_scratch && !chunk_totals) return em::fail(EM_ERR_INVALID, "em_rollout_index: scan_scratch is required");
     if (ro->n_nodes > 64) return em::fail(EM_ERR_INVALID, "em_rollout_index: n_nodes must be <= 64");
-    if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0 || (reinterpret_cast<uintptr_t>(ro->st_state) & 15) != 0)
+    const int64_t B = ro->n_envs;
+    const int64_t sw = (int64_t)ro->n_nodes * (ro->n_nodes + 4);
+    int64_t row_base = 0;
+    if (!ro->st_state) {
+        // states by reference: obs must be a whole slice of the rollout's observation history
+        if (!ro->obs_tb || !ro->st_row) return em::fail(EM_ERR_INVALID, "em_rollout_index: st_state is NULL, so obs_tb and st_row are required");
+        const int64_t off = obs - ro->obs_tb;
+        if (off < 0 || off % (B * sw) != 0) return em::fail(EM_ERR_INVALID, "em_rollout_index: obs is not a slice of obs_tb");
+        row_base = off / sw;
+        if (row_base + B > 0x7fffffffll) return em::fail(EM_ERR_INVALID, "em_rollout_index: observation history exceeds 2^31 rows");
+    } else if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0 || (reinterpret_cast<uintptr_t>(ro->st_state) & 15) != 0)
         return em::fail(EM_ERR_INVALID, "em_rollout_index: obs and st_state must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t B = ro->n_envs;
     const int64_t chunks = (B + CHUNK - 1) / CHUNK;
-    unsigned long long* tot = reinterpret_cast<unsigned long long*>(ro->scan_scratch);
-    hipLaunchKernelGGL(rollout_count_kernel, dim3((unsigned)chunks), dim3(CHUNK), 0, s, B, active, tot);
+    const unsigned long long* tot = reinterpret_cast<const unsigned long long*>(chunk_totals);
+    if (!tot) {
+        unsigned long long* own = reinterpret_cast<unsigned long long*>(ro->scan_scratch);
+        hipLaunchKernelGGL(rollout_count_kernel, dim3((unsigned)chunks), dim3(CHUNK), 0, s, B, active, own);
+        tot = own;
+    }
     hipLaunchKernelGGL(rollout_scan_compact_kernel, dim3((unsigned)chunks), dim3(CHUNK), 0, s, B, ro->n_nodes, t, active, rank,
                        obs, tot, (int)chunks, ro->counters, ro->k_tb + (int64_t)t * B, ro->first_tb + (int64_t)t * B, ro->srow,
                        ro->capacity_entries, ro->capacity_steps, ro->err_flag, ro->ent_obs, ro->ent_env, ro->ent_agent,
-                       ro->st_state, ro->st_env, ro->st_first, ro->st_k);
+                       ro->st_state, ro->st_env, ro->st_first, ro->st_k, ro->st_row, row_base,
+                       reinterpret_cast<unsigned long long*>(chunk_totals_next));
     return em::hip_check(hipGetLastError(), "rollout index/compact launch");
+}
+}  // namespace
+
+extern "C" {
+
+int em_rollout_index(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
+                     void* stream)
+{
+    return rollout_index_impl(ro, t, active, rank, obs, nullptr, nullptr, stream);
+}
+
+int em_rollout_index_totals(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
+                            const uint64_t* chunk_totals, uint64_t* chunk_totals_next, void* stream)
+{
+    if (!chunk_totals) return em::fail(EM_ERR_INVALID, "em_rollout_index_totals: chunk_totals is required");
+    return rollout_index_impl(ro, t, active, rank, obs, chunk_totals, chunk_totals_next, stream);
 }
 
 int em_value_step(const em_rollout* ro, int32_t t, const em_mlp3* critic, float value_norm_mean, float value_norm_var, void* stream)
@@ -671,7 +760,12 @@ int em_value_step(const em_rollout* ro, int32_t t, const em_mlp3* critic, float 
         return em::fail(EM_ERR_INVALID, "em_value_step: network shape does not match n_nodes=%d", n);
     FwdArgs fc;
     std::memset(&fc, 0, sizeof fc);
-    fc.net = *critic; fc.x = ro->st_state; fc.ldx = (int64_t)n * (n + 4); fc.dyn = ro->counters + 4 * t + 2;
+    fc.net = *critic; fc.ldx = (int64_t)n * (n + 4); fc.dyn = ro->counters + 4 * t + 2;
+    if (ro->st_state) fc.x = ro->st_state;
+    else {                                   // states by reference: rows of the observation history
+        if (!ro->obs_tb || !ro->st_row) return em::fail(EM_ERR_INVALID, "em_value_step: st_state is NULL, so obs_tb and st_row are required");
+        fc.x = ro->obs_tb; fc.x_rows = ro->st_row;
+    }
     fc.st_value = ro->st_value; fc.st_env = ro->st_env; fc.value_tb = ro->value_tb + (int64_t)t * ro->n_envs;
     fc.norm_mean = value_norm_mean; fc.norm_scale = sqrtf(value_norm_var + 1e-8f);
     return launch_fwd<2>(fc, ro->n_envs, (hipStream_t)stream);

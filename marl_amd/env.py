@@ -100,6 +100,19 @@ class BatchedEdgeSimGym:
         o.n_draws = self.n_draws.data_ptr() if self.n_draws is not None else None
         o.reward_seen = self.reward.data_ptr()
 
+    def bind_obs(self, obs: torch.Tensor | None = None, chunk_totals: torch.Tensor | None = None):
+        """Redirect the observation output of the following reset/step calls into ``obs`` ([B, N, N+4] float32,
+        contiguous, e.g. a slice of a rollout's observation history) - ``self.obs`` then IS that tensor - and/or let the
+        kernel add its per-256-environment acting-agent totals into ``chunk_totals`` (``em_step_out.chunk_totals``;
+        ``None`` switches that output off)."""
+        if obs is not None:
+            B, n = self.n_envs, self.n_nodes
+            if tuple(obs.shape) != (B, n, n + 4) or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.device != self.device:
+                raise ValueError(f"obs must be a contiguous float32 [{B}, {n}, {n + 4}] tensor on {self.device}")
+            self.obs = obs
+            self._out.obs = obs.data_ptr()
+        self._out.chunk_totals = chunk_totals.data_ptr() if chunk_totals is not None else None
+
     def enable_debug_outputs(self):
         """Also produce per-slot latencies and draw counts each step (parity tests)."""
         B, n = self.n_envs, self.n_nodes

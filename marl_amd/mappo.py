@@ -242,10 +242,17 @@ class RolloutStorage:
     reference's ``add/get`` list interface is kept beside it (``staged``): transitions added one at a time are uploaded by
     ``MAPPO.update()``."""
 
-    def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None, entries_per_step=2.2):
+    def __init__(self, n_envs, n_nodes, horizon, device, capacity_entries=None, capacity_steps=None, entries_per_step=2.2,
+                 by_reference=False):
         """``entries_per_step``: bound on the MEAN number of acting agents per environment step used to size large
         batches (small ones get the exact worst case n_nodes); :func:`marl_amd.config.mean_arrivals_bound` derives it
-        from the arrival-rate range and the time-step clip of an ENV_CONFIG."""
+        from the arrival-rate range and the time-step clip of an ENV_CONFIG.
+
+        ``by_reference``: states are not copied.  The storage keeps the dense observation tensor of every step
+        (``obs_tb`` [horizon + 1, B, n, n + 4]: the environment writes each step's observations straight into the next
+        slice, see ``obs_slice``) and a state is a row number there (``st_row``).  Same HBM footprint as the worst-case
+        compact copy, but recording a step moves only the acting agents' rows instead of re-reading and re-writing the
+        whole observation tensor."""
         B, n, T = int(n_envs), int(n_nodes), int(horizon)
         w, A = n + 4, n + 1
         if capacity_steps is None:
@@ -257,13 +264,21 @@ class RolloutStorage:
         E, S = self.capacity_entries, self.capacity_steps
         f32, i32, u8 = torch.float32, torch.int32, torch.uint8
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        self.by_reference = bool(by_reference)
         self.t = OrderedDict(
             ent_obs=z((E, w), f32), ent_action=z((E, A), f32), ent_logp=z(E, f32), ent_env=z(E, i32),
             ent_agent=z(E, torch.int8), ent_adv=z(E, f32), ent_ret=z(E, f32),
-            st_state=z((S, n * w), f32), st_value=z(S, f32), st_env=z(S, i32), st_first=z(S, i32), st_k=z(S, u8),
+            st_state=None if by_reference else z((S, n * w), f32), st_value=z(S, f32), st_env=z(S, i32), st_first=z(S, i32),
+            st_k=z(S, u8),
             reward_tb=z((T, B), torch.float64), done_tb=z((T, B), u8), value_tb=z((T, B), f32), k_tb=z((T, B), u8),
-            first_tb=z((T, B), i32), srow=z(B, i32), scan_scratch=z((B + 63) // 64, torch.int64), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32))
-        self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() for v in self.t.values()])
+            first_tb=z((T, B), i32), srow=z(B, i32), scan_scratch=z((B + 63) // 64, torch.int64), counters=z((T + 1, 4), torch.int64), err_flag=z(1, i32),
+            obs_tb=z((T + 1, B, n, w), f32) if by_reference else None, st_row=z(S, i32) if by_reference else None)
+        if by_reference and (T + 1) * B > 2**31 - 1:
+            raise ValueError("the observation history would exceed 2^31 rows; use a smaller horizon or by_reference=False")
+        self.struct = _lib.EmRollout(B, E, S, n, T, *[v.data_ptr() if v is not None else None for v in self.t.values()])
+        # per-256-environment totals of acting agents, written by the environment kernel (em_step_out.chunk_totals) and
+        # consumed by em_rollout_index_totals; two buffers used alternately (see MAPPO.record_and_act)
+        self.chunk_totals = z((2, (B + 255) // 256), torch.int64)
         self.ref = C.byref(self.struct)
         self.steps_recorded = 0
         self.staged = RolloutBuffer()
@@ -273,6 +288,18 @@ class RolloutStorage:
         self.t["k_tb"].zero_()
         self.steps_recorded = 0
         self.staged.clear()
+
+    def obs_slice(self, i):
+        """Slice ``i`` of the observation history (by-reference storage): where the observations at the START of recorded
+        step ``i`` live.  Slices wrap, so a one-step scratch storage can be used ping-pong."""
+        return self.t["obs_tb"][i % self.t["obs_tb"].shape[0]]
+
+    def state_rows(self, n_states):
+        """The first ``n_states`` state rows as a tensor [n_states, n*(n+4)] (copy), whatever the storage mode."""
+        if not self.by_reference:
+            return self.t["st_state"][:n_states]
+        flat = self.t["obs_tb"].view(-1, self.n_nodes * (self.n_nodes + 4))
+        return flat[self.t["st_row"][:n_states].long()]
 
     # the reference's list interface (mappo_algorithm.py:104-131)
     def add(self, obs, state, action, reward, done, log_prob, value):
@@ -343,7 +370,7 @@ class MAPPO:
 
     def __init__(self, obs_dim, state_dim, action_dim, n_agents, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip_param=0.2,
                  value_loss_coeff=0.5, entropy_coeff=0.01, max_grad_norm=0.5, num_sgd_iter=4, device="cuda:0",
-                 n_envs=1, horizon=1000, process_group=None, capacity_entries=None, entries_per_step=2.2):
+                 n_envs=1, horizon=1000, process_group=None, capacity_entries=None, entries_per_step=2.2, by_reference=True):
         self.obs_dim, self.state_dim, self.action_dim, self.n_agents = obs_dim, state_dim, action_dim, n_agents
         self.gamma, self.gae_lambda, self.clip_param = gamma, gae_lambda, clip_param
         self.value_loss_coeff, self.entropy_coeff = value_loss_coeff, entropy_coeff
@@ -368,7 +395,7 @@ class MAPPO:
         self.critic_optimizer = HipAdam(self.critic, lr)
         self.value_normalizer = ValueNormalizer(1, device=self.device)
         self.buffer = RolloutStorage(n_envs, n_agents, horizon, self.device, capacity_entries=capacity_entries,
-                                     entries_per_step=entries_per_step)
+                                     entries_per_step=entries_per_step, by_reference=by_reference)
         self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._gae_partials = torch.zeros(3 * ((n_envs + 255) // 256), dtype=torch.float64, device=self.device)
         self._slab_a = self._slab_c = None
@@ -391,7 +418,7 @@ class MAPPO:
         return float(self.value_normalizer.running_mean.reshape(-1)[0]), float(self.value_normalizer.running_var.reshape(-1)[0])
 
     def record_and_act(self, t, obs, active, rank, placement_out, resource_out, explore=True, noise=None, seed=0,
-                       episode=0, env_offset=0, rng_step=None):
+                       episode=0, env_offset=0, rng_step=None, totals=None, totals_next=None):
         """Steps 199-219 of MAPPOTrainer.train_episode for all environments: index the acting agents, sample
         their actions, format the env actions and evaluate the critic on the pre-step state."""
         ro = self.buffer
@@ -401,7 +428,12 @@ class MAPPO:
         with torch.cuda.device(self.device):
             main = torch.cuda.current_stream(self.device)
             s = int(main.cuda_stream)
-            _lib.check(L.em_rollout_index(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s), "em_rollout_index")
+            if totals is not None:       # the environment kernel already counted the acting agents per chunk
+                _lib.check(L.em_rollout_index_totals(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(),
+                                                     totals.data_ptr(), totals_next.data_ptr() if totals_next is not None else None,
+                                                     s), "em_rollout_index_totals")
+            else:
+                _lib.check(L.em_rollout_index(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s), "em_rollout_index")
             fused_critic = c_ref
             if self.overlap_value:
                 if self._side is None:
@@ -550,10 +582,12 @@ class MAPPO:
                                        self.moments.data_ptr(), E, n_global, float(self.clip_param),
                                        float(self.entropy_coeff), self._slab_a.data_ptr(), wa, g.data_ptr(),
                                        loss_a.data_ptr(), s), "em_ppo_actor_grad")
-        _lib.check(L.em_ppo_critic_grad(C.byref(c_net), t["st_state"].data_ptr(), t["st_first"].data_ptr(),
-                                        t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
-                                        float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
-                                        g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
+        by_ref = t["st_state"] is None
+        _lib.check(L.em_ppo_critic_grad_rows(C.byref(c_net), (t["obs_tb"] if by_ref else t["st_state"]).data_ptr(),
+                                             t["st_row"].data_ptr() if by_ref else None, t["st_first"].data_ptr(),
+                                             t["st_k"].data_ptr(), t["ent_ret"].data_ptr(), S, n_global,
+                                             float(self.value_loss_coeff), mean, var, self._slab_c.data_ptr(), wc,
+                                             g[na:].data_ptr(), loss_c.data_ptr(), s), "em_ppo_critic_grad")
 
     # -- dict API of the reference (mappo_algorithm.py:189-239), one environment -------------------------------
     def get_actions(self, observations, explore=True, noise=None):

@@ -75,16 +75,24 @@ class MAPPOTrainer:
             m.buffer = self._train_storage
         else:   # evaluation episodes must not clobber a recorded batch (run_mappo_batch.py:272-317 evaluates first)
             if self._scratch_storage is None:
-                self._scratch_storage = RolloutStorage(self.n_envs, self.n_agents, 1, self.device)
+                self._scratch_storage = RolloutStorage(self.n_envs, self.n_agents, 1, self.device, by_reference=True)
             m.buffer = self._scratch_storage
         ro = m.buffer
-        env.reset(tape=tapes[0] if tapes is not None else None)
         # like the reference's list buffer, recorded episodes accumulate until update() clears them
         # (mappo_trainer.py:281-282); the storage holds update_interval episodes
         base = ro.steps_recorded if record_buffer else 0
         if record_buffer and base + T > ro.horizon:
             raise RuntimeError(f"rollout storage holds {ro.horizon // T} episode(s): call mappo.update() or construct "
                                "MAPPOTrainer with a larger update_interval")
+        # The environment writes the observations of step t + 1 straight into slice t + 1 of the storage's observation
+        # history (states are held by reference, nothing is copied) and counts the acting agents per 256-environment chunk
+        # on the way out; the two total buffers alternate, em_rollout_index_totals clears the one the next step adds into.
+        tot = ro.chunk_totals
+        tot.zero_()
+        par = 0
+        own_obs = env.obs
+        env.bind_obs(ro.obs_slice(base) if ro.by_reference else None, tot[par])
+        env.reset(tape=tapes[0] if tapes is not None else None)
         if base == 0:
             m.begin_rollout()
         self.policy_episode += 1
@@ -95,7 +103,9 @@ class MAPPOTrainer:
                 slot = base + t if record_buffer else 0
                 m.record_and_act(slot, env.obs, env.active, env.rank, self.placement, self.resource, explore=explore,
                                  noise=noise, seed=self.seed, episode=self.policy_episode, env_offset=self.env_offset,
-                                 rng_step=t)
+                                 rng_step=t, totals=tot[par], totals_next=tot[par ^ 1])
+                par ^= 1
+                env.bind_obs(ro.obs_slice(base + t + 1) if ro.by_reference else None, tot[par])
                 if record_buffer:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None,
                              reward_seen_out=ro.t["reward_tb"][slot], done_out=ro.t["done_tb"][slot])
@@ -106,6 +116,11 @@ class MAPPOTrainer:
             m.overlap_value = False
             m.join_value()
             m.buffer = self._train_storage
+            # the environment keeps its last observation in the storage's slice: callers that step it by hand afterwards get
+            # its own buffer back (with the current observation in it)
+            if ro.by_reference:
+                own_obs.copy_(env.obs)
+            env.bind_obs(own_obs if ro.by_reference else None, None)
         if record_buffer:
             total_reward = ro.t["reward_tb"][base:base + T].sum(dim=0)
         metrics = env.episode_metrics()                      # [B, 6] on the device

@@ -37,7 +37,7 @@ def test_struct_sizes_match_header():
     from marl_amd.config import EmConfig
     assert ctypes.sizeof(EmConfig) == 16 + 64 * 8 + 21 * 8 + 8 == 704
     assert ctypes.sizeof(_lib.EmTape) == 12 * 8 + 8
-    assert ctypes.sizeof(_lib.EmStepOut) == 9 * 8
+    assert ctypes.sizeof(_lib.EmStepOut) == 10 * 8
 
 
 def test_no_cpu_fallback():

@@ -27,12 +27,18 @@ def _trainer(n_envs, rank):
     return MAPPOTrainer(dict(ENV_CONFIG), seed=0, device="cuda:0", n_envs=n_envs, rank=rank, world_size=1, verbose=False)
 
 
+def _state_rows(t, idx):
+    """State rows by index: the storage holds them by reference (rows of the observation history)."""
+    flat = t["obs_tb"].view(-1, 140)
+    return flat[t["st_row"][idx].long()]
+
+
 def _env_rows(t, E, S, env):
     """Everything the storage holds about one environment, in recording order."""
     sel = (t["ent_env"][:E] == env).nonzero().squeeze(1)
     ssel = (t["st_env"][:S] == env).nonzero().squeeze(1)
     return {"obs": t["ent_obs"][sel], "action": t["ent_action"][sel], "logp": t["ent_logp"][sel], "agent": t["ent_agent"][sel],
-            "adv": t["ent_adv"][sel], "ret": t["ent_ret"][sel], "state": t["st_state"][ssel], "value": t["st_value"][ssel],
+            "adv": t["ent_adv"][sel], "ret": t["ent_ret"][sel], "state": _state_rows(t, ssel), "value": t["st_value"][ssel],
             "k": t["st_k"][ssel], "reward": t["reward_tb"][:, env], "done": t["done_tb"][:, env], "k_tb": t["k_tb"][:, env]}
 
 
@@ -64,7 +70,8 @@ def test_configs2_full_size_rollout_gae_update():
     assert int(t["st_first"][S - 1].item()) + int(t["st_k"][S - 1].item()) == E
     w = 14
     ag = int(t["ent_agent"][E - 1].item())
-    assert torch.equal(t["st_state"][S - 1].view(10, w)[ag], t["ent_obs"][E - 1])
+    assert torch.equal(_state_rows(t, torch.tensor([S - 1], device="cuda"))[0].view(10, w)[ag], t["ent_obs"][E - 1])
+    assert int(t["st_row"][S - 1].item()) == (T - 1) * B + last_env          # row of (last step, env) in the history
     m.compute_gae()
     mom = m.moments.cpu().numpy()
     assert mom[0] == E
@@ -86,7 +93,7 @@ def test_configs2_full_size_rollout_gae_update():
         chunk = 1 << 21
         for lo in range(0, S, chunk):
             hi = min(S, lo + chunk)
-            h = torch.relu(torch.addmm(crit[1], t["st_state"][lo:hi], crit[0].t()))
+            h = torch.relu(torch.addmm(crit[1], _state_rows(t, slice(lo, hi)), crit[0].t()))
             h = torch.relu(torch.addmm(crit[3], h, crit[2].t()))
             v = torch.addmm(crit[5], h, crit[4].t()).squeeze(1)
             first, k = t["st_first"][lo:hi].long(), t["st_k"][lo:hi].long()

@@ -58,10 +58,10 @@ def test_rollout_gae_update_parity():
         ro = m.buffer
         E, S = ro.totals()
         assert E == L and S == len(np.unique(step_of))
-        t = {k: v.cpu().numpy() for k, v in ro.t.items()}
+        t = {k: v.cpu().numpy() for k, v in ro.t.items() if v is not None}
         # environment side: bit-exact (observations prove that every placement/resource decision matched)
         assert np.array_equal(t["ent_obs"][:E], obs_flat)
-        assert np.array_equal(t["st_state"][:S], states_flat[np.unique(step_of, return_index=True)[1]])
+        assert np.array_equal(ro.state_rows(S).cpu().numpy(), states_flat[np.unique(step_of, return_index=True)[1]])
         rew = np.where(g["step_emitted"], g["step_reward"], 0.0)
         np.testing.assert_allclose(t["reward_tb"][:, 0], rew, rtol=1e-6, atol=0)
         assert abs(stats["episode_reward"] - float(g["episode_reward"])) <= 1e-6 * abs(float(g["episode_reward"]))
@@ -146,7 +146,7 @@ def test_update_interval_two_accumulates_episodes_like_the_list_buffer():
     assert ro.steps_recorded == 2 * T and E > 0
     m.compute_gae()
     torch.cuda.synchronize()
-    t = {k: v.cpu().numpy() for k, v in ro.t.items()}
+    t = {k: v.cpu().numpy() for k, v in ro.t.items() if v is not None}
     n_leaks = 0
     for b in range(B):
         rewards, values, dones, slots = [], [], [], []
@@ -167,3 +167,36 @@ def test_update_interval_two_accumulates_episodes_like_the_list_buffer():
     assert ro.steps_recorded == 0 and np.isfinite(out["critic_loss"])
     tr.train_episode(explore=True, record_buffer=True)     # storage is free again
     print("episodes that leak into the next one:", n_leaks, "of", B)
+
+
+def test_states_by_reference_equal_compact_copies():
+    """The two storage modes of the rollout (states copied compactly vs held by reference in the observation history, with
+    the acting-agent totals counted by the environment kernel instead of a counting launch) record the same transitions and
+    give the same update, bit for bit."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.mappo import RolloutStorage
+    from marl_amd.trainer import MAPPOTrainer
+    cfg = dict(ENV_CONFIG, episode_length=50)
+    B = 700                                      # three 256-environment chunks, the last one partial
+    outs = []
+    for by_ref in (True, False):
+        tr = MAPPOTrainer(cfg, seed=4, device="cuda:0", n_envs=B, verbose=False)
+        if not by_ref:
+            tr.mappo.buffer = tr._train_storage = RolloutStorage(B, 10, 50, tr.device, by_reference=False)
+        assert tr.mappo.buffer.by_reference == by_ref
+        tr.train_episode(explore=True, record_buffer=True)
+        ro = tr.mappo.buffer
+        E, S = ro.totals()
+        rec = {k: ro.t[k][:E].clone() for k in ("ent_obs", "ent_action", "ent_logp", "ent_env", "ent_agent")}
+        rec.update({k: ro.t[k][:S].clone() for k in ("st_value", "st_env", "st_first", "st_k")})
+        rec.update(states=ro.state_rows(S).clone(), k_tb=ro.t["k_tb"].clone(), first_tb=ro.t["first_tb"].clone(),
+                   reward=ro.t["reward_tb"].clone(), counters=ro.t["counters"].clone())
+        out = tr.mappo.update()
+        rec["params"] = tr.mappo.flat_params.clone()
+        outs.append((rec, out, E, S))
+        ev = tr.evaluate(num_episodes=B)          # the one-step scratch storage is by reference too (two slices, ping-pong)
+        assert np.isfinite(ev["avg_latency_ms"])
+    (a, oa, Ea, Sa), (b, ob, Eb, Sb) = outs
+    assert (Ea, Sa) == (Eb, Sb) and Ea > 1000 and oa == ob
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
