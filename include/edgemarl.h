@@ -359,6 +359,13 @@ int em_policy_step(const em_rollout *ro, int32_t t, const em_mlp3 *actor, const 
 int em_value_step(const em_rollout *ro, int32_t t, const em_mlp3 *critic, float value_norm_mean, float value_norm_var,
                   void *stream);
 
+/* MAPPO.get_values (mappo_algorithm.py:226-239) for ALL states of a rollout that holds them by reference, in one launch:
+ * the parameters do not change during a rollout and nothing before em_gae reads a value, so the critic need not run once
+ * per step (a thousand latency-bound launches) - the same rows through the same kernel give the same bits.  Slice i of
+ * obs_tb must hold the observations of recorded step i (value_tb[st_row[s]] receives the value of state s). */
+int em_value_all(const em_rollout *ro, int64_t n_states, const em_mlp3 *critic, float value_norm_mean, float value_norm_var,
+                 void *stream);
+
 /* MAPPO.compute_gae (mappo_algorithm.py:241-262) for every environment's segment of the transition
  * list (next_value = 0 per segment, :284), float64 recursion, results rounded to float32 into
  * ro->ent_adv / ro->ent_ret.  moments3 (device, 3 doubles) receives {count, sum, sum of squares} of the

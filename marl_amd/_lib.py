@@ -158,6 +158,8 @@ def lib() -> C.CDLL:
                                  C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.em_value_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
     L.em_value_step.restype = C.c_int
+    L.em_value_all.argtypes = [C.POINTER(EmRollout), i64, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
+    L.em_value_all.restype = C.c_int
     f32, f64 = C.c_float, C.c_double
     L.em_gae.argtypes = [C.POINTER(EmRollout), f64, f64, vp, i64, vp, vp]
     L.em_gae_static.argtypes = [C.POINTER(EmRollout), f64, f64, vp, vp]

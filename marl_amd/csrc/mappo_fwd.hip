@@ -771,6 +771,29 @@ int em_value_step(const em_rollout* ro, int32_t t, const em_mlp3* critic, float 
     return launch_fwd<2>(fc, ro->n_envs, (hipStream_t)stream);
 }
 
+int em_value_all(const em_rollout* ro, int64_t n_states, const em_mlp3* critic, float value_norm_mean, float value_norm_var,
+                 void* stream)
+{
+    if (!ro) return em::fail(EM_ERR_INVALID, "em_value_all: null argument");
+    if (!ro->obs_tb || !ro->st_row || ro->st_state)
+        return em::fail(EM_ERR_INVALID, "em_value_all: the rollout must hold its states by reference (obs_tb, st_row)");
+    if (n_states < 0 || n_states > ro->capacity_steps) return em::fail(EM_ERR_INVALID, "em_value_all: n_states outside the storage");
+    int rc = check_net(critic);
+    if (rc) return rc;
+    const int n = ro->n_nodes;
+    if (critic->in_dim != n * (n + 4) || critic->out_dim != 1)
+        return em::fail(EM_ERR_INVALID, "em_value_all: network shape does not match n_nodes=%d", n);
+    if (n_states == 0) return EM_OK;
+    FwdArgs fc;
+    std::memset(&fc, 0, sizeof fc);
+    fc.net = *critic; fc.ldx = (int64_t)n * (n + 4); fc.n_rows = n_states;
+    fc.x = ro->obs_tb; fc.x_rows = ro->st_row;
+    // a state's row number in the observation history is also its (step, environment) position in the dense arrays
+    fc.st_value = ro->st_value; fc.st_env = ro->st_row; fc.value_tb = ro->value_tb;
+    fc.norm_mean = value_norm_mean; fc.norm_scale = sqrtf(value_norm_var + 1e-8f);
+    return launch_fwd<2>(fc, n_states, (hipStream_t)stream);
+}
+
 int em_policy_step(const em_rollout* ro, int32_t t, const em_mlp3* actor, const float* log_std, const em_mlp3* critic,
                    float value_norm_mean, float value_norm_var, const float* noise, int explore, uint64_t seed,
                    uint32_t episode, uint32_t rng_step, uint64_t env_offset, int32_t* placement, float* resource, void* stream)

@@ -407,11 +407,30 @@ class MAPPO:
         self.overlap_value = False
         self._side = self._ev_idx = self._ev_val = None
         self._value_pending = False
+        # With the states held by reference the critic does not run during the rollout at all: one launch over every
+        # recorded state before GAE (em_value_all) replaces a thousand small ones; same rows, same kernel, same bits.
+        self.defer_values = True
+        self._values_through = 0          # recorded steps whose values have been computed
 
     def join_value(self):
         if self._value_pending:
             torch.cuda.current_stream(self.device).wait_event(self._ev_val)
             self._value_pending = False
+
+    def _deferred(self):
+        return self.defer_values and self.buffer.by_reference and self.buffer.horizon > 1
+
+    def compute_values(self):
+        """Values of every recorded state that does not have one yet (deferred mode); a no-op otherwise."""
+        ro = self.buffer
+        if not self._deferred() or ro.steps_recorded == 0 or self._values_through == ro.steps_recorded:
+            return
+        n_states = int(ro.t["counters"][ro.steps_recorded, 2].item())
+        mean, var = self._norm()
+        c_net = self.critic.net()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.em_value_all(ro.ref, n_states, C.byref(c_net), mean, var, _stream(self.device)), "em_value_all")
+        self._values_through = ro.steps_recorded
 
     # -- rollout side ----------------------------------------------------------------------------------
     def _norm(self):
@@ -435,7 +454,9 @@ class MAPPO:
             else:
                 _lib.check(L.em_rollout_index(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), s), "em_rollout_index")
             fused_critic = c_ref
-            if self.overlap_value:
+            if self._deferred():
+                fused_critic = None
+            elif self.overlap_value:
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
                     self._ev_idx, self._ev_val = torch.cuda.Event(), torch.cuda.Event()
@@ -453,6 +474,7 @@ class MAPPO:
 
     def begin_rollout(self):
         self.buffer.clear()
+        self._values_through = 0
         self._norm_cached = self._norm()
         self._cache_nets()
 
@@ -471,6 +493,7 @@ class MAPPO:
             return self._compute_gae_lists(rewards, values, dones, next_value)
         ro = self.buffer
         self.join_value()
+        self.compute_values()
         with torch.cuda.device(self.device):
             _lib.check(self._L.em_gae(C.byref(ro.struct), float(self.gamma), float(self.gae_lambda),
                                       self._gae_partials.data_ptr(), self._gae_partials.numel(), self.moments.data_ptr(),
@@ -522,9 +545,11 @@ class MAPPO:
         if err_g:
             msg = ro.overflow_message(E, S) if err else "rollout storage capacity exceeded on another rank"
             ro.clear()
+            self._values_through = 0
             raise RuntimeError(msg)
         if recorded_g == 0 or E_g == 0:
             ro.clear()
+            self._values_through = 0
             return {}
         if ro.steps_recorded:
             self.compute_gae()
@@ -567,6 +592,7 @@ class MAPPO:
                                           self.grad_norms.data_ptr(), s), "em_adam_step")
                 acc += g[na + nc:]          # per-epoch loss sums (already global after the all-reduce)
         ro.clear()
+        self._values_through = 0
         sums = acc.cpu()
         k = float(self.num_sgd_iter) * n_global
         self.last_update = {"actor_loss": float(-sums[0] / k), "critic_loss": float(0.5 * sums[4] / k),

@@ -122,6 +122,7 @@ class MAPPOTrainer:
                 own_obs.copy_(env.obs)
             env.bind_obs(own_obs if ro.by_reference else None, None)
         if record_buffer:
+            m.compute_values()            # deferred critic: one launch over the recorded states (a no-op in the per-step modes)
             total_reward = ro.t["reward_tb"][base:base + T].sum(dim=0)
         metrics = env.episode_metrics()                      # [B, 6] on the device
         # the reference harvests the metrics only when the final step produced observations
