@@ -135,12 +135,20 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
         entries, states = tr.mappo.buffer.totals()
         tr.mappo.update()
         torch.cuda.synchronize(device)
-        flops[0] += 3.0 * tr.mappo.num_sgd_iter * (11392.0 * entries + 26240.0 * states)   # fwd + 2x bwd per epoch
+        ep = float(tr.mappo.num_sgd_iter)
+        # three ways to count one epoch of the update's two fused forward+backward kernels over this rank's rows:
+        #  survey  SURVEY.md 8d's convention, 3 x forward FLOPs (it charges a first-layer dX product nobody computes)
+        #  useful  forward + every weight gradient + dX of layers 2 and 3: actor 32,384, critic 60,800 FLOP per row
+        #  issue   matrix-core instructions actually issued (padded 16-row tiles: 272 / 528 v_mfma_f32_16x16x4_f32 per tile,
+        #          32 cycles each on one of 1,024 SIMDs) as seconds at the 2.4 GHz the chip sustains
+        flops["survey"] += 3.0 * ep * (11392.0 * entries + 26240.0 * states)
+        flops["useful"] += ep * (32384.0 * entries + 60800.0 * states)
+        flops["issue_s"] += ep * (272.0 * ((entries + 15) // 16) + 528.0 * ((states + 15) // 16)) * 32.0 / (1024.0 * 2.4e9)
         return entries, t1 - t0, time.perf_counter() - t1
 
-    flops = [0.0]
+    flops = {"survey": 0.0, "useful": 0.0, "issue_s": 0.0}
     iteration()                                   # warmup: allocator, code objects, RCCL channels
-    flops[0] = 0.0
+    flops = {"survey": 0.0, "useful": 0.0, "issue_s": 0.0}
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -174,9 +182,15 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
             "update_s_rank0": upd / iters, "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
             # the update is the GEMM-shaped part: algorithmic FLOPs of rank 0's actor/critic forward + backward over its
             # wall time (GAE, reductions and Adam included) against the dense f32 matrix-core peak
-            "update_roofline": {"bound": "mfma", "achieved": flops[0] / max(upd, 1e-9) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                "frac": flops[0] / max(upd, 1e-9) / 1e12 / 157.3,
-                                "note": "actor 14-64-64-11 over the transitions, critic 140-64-64-1 once per (env, step)"},
+            "update_roofline": {"bound": "mfma", "achieved": flops["useful"] / max(upd, 1e-9) / 1e12, "peak": 157.3,
+                                "unit": "TFLOP/s", "frac": flops["useful"] / max(upd, 1e-9) / 1e12 / 157.3,
+                                "mfma_issue_frac": flops["issue_s"] / max(upd, 1e-9),
+                                "survey_convention_frac": flops["survey"] / max(upd, 1e-9) / 1e12 / 157.3,
+                                "note": "achieved/frac: useful FLOPs (forward + weight gradients + dX of layers 2-3; actor "
+                                        "32,384, critic 60,800 per row and epoch) over the update's whole wall time (GAE, "
+                                        "reductions, Adam included); mfma_issue_frac: time the issued MFMA instructions need "
+                                        "at 2.4 GHz over the same wall time; survey_convention_frac: 3 x forward FLOPs"},
+            "rollout": "states by reference, acting-agent totals from the step kernel, one critic launch per episode",
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 
@@ -419,8 +433,10 @@ def scaled_leg(device, rank, world, B=65536, steps=300):
             "entry_point": "ems_step", "n_envs_per_gpu": B, "steps": steps, "env_steps_per_s": world * B * steps / elapsed,
             "value": world * B * D * steps / elapsed, "unit": "agent-steps/s", "mean_pending_per_step": kbar,
             "avg_launch_us": dev_ms * 1e3 / steps,
-            "roofline": {"bound": "hbm", "kernel": "scaled_env_kernel<step>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
+            "roofline": {"bound": "hbm", "kernel": "scaled_env4_kernel<step>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic_for(f"scaled_env4_kernel@{B}", "scaled")[0],
+                         "traffic_source": traffic_for(f"scaled_env4_kernel@{B}", "scaled")[1],
+                         "bytes_per_env_step": per_step, "bytes_per_launch": per_step * B}}
 
 
 def marl_env_leg(device, rank, world, B=65536, steps=400, lanes=0):
@@ -477,7 +493,9 @@ def marl_env_leg(device, rank, world, B=65536, steps=400, lanes=0):
             "entry_point": "emm_step", "n_envs_per_gpu": B, "steps": steps, "env_steps_per_s": world * B * steps / elapsed,
             "value": world * B * n * steps / elapsed, "unit": "agent-steps/s", "avg_launch_us": dev_ms * 1e3 / steps,
             "roofline": {"bound": "hbm", "kernel": "marl_env_kernel<step>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": per_step}}
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic_for(f"marl_env_kernel@{B}", "marl")[0],
+                         "traffic_source": traffic_for(f"marl_env_kernel@{B}", "marl")[1],
+                         "bytes_per_env_step": per_step, "bytes_per_launch": per_step * B}}
 
 
 def guarded(name, fn, *a, **k):
@@ -491,26 +509,33 @@ def guarded(name, fn, *a, **k):
         return {"error": repr(e)[:300]}
 
 
-def kernel_signature() -> str:
-    """Hash of the env-step kernel's sources: a PMC traffic figure is only echoed for the code it was measured on."""
+_SRC = {"env": ("edge_env.hip", "em_env_math.h", "em_common.h"),
+        "scaled": ("edge_env_scaled.hip", "em_env_math.h", "em_common.h"),
+        "marl": ("edge_marl_env.hip", "em_env_math.h", "em_common.h")}
+
+
+def kernel_signature(which: str = "env") -> str:
+    """Hash of a step kernel's sources: a PMC traffic figure is only echoed for the code it was measured on."""
     import hashlib
     hsh = hashlib.sha1()
-    for name in ("edge_env.hip", "em_env_math.h", "em_common.h"):
+    for name in _SRC[which]:
         with open(os.path.join(ROOT, "marl_amd", "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()[:16]
 
 
-def traffic_for(B):
-    """HBM bytes per em_step launch from the separate rocprofv3 --pmc passes of tools/measure_traffic.sh (counters cannot
-    be read from inside this process).  profiles/traffic.json records the kernel signature it was measured on; a figure
-    taken on other kernel code is omitted (null), never echoed.  Returns (bytes or None, provenance string or None)."""
+def traffic_for(key, which: str = "env"):
+    """HBM bytes per launch of a step kernel from the separate rocprofv3 --pmc passes of tools/measure_traffic.sh (the
+    counters cannot be read from inside this process).  profiles/traffic.json records, per entry, the hash of the kernel
+    sources it was measured on; a figure taken on other kernel code is omitted (null), never echoed.  Returns
+    (bytes or None, provenance string or None)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         doc = json.load(open(tpath))
-        if doc.get("kernel_signature") != kernel_signature():
+        key = str(key)
+        if doc.get("signatures", {}).get(key) != kernel_signature(which):
             return None, None
-        v = doc.get(str(B))
+        v = doc.get(key)
         return (v, f"profiles/traffic.json ({doc.get('measured', 'tools/measure_traffic.sh')})") if v is not None else (None, None)
     except Exception:
         return None, None
