@@ -50,6 +50,16 @@ __host__ __device__ inline int rec_off_queue(int n) { return 32 * n + 32; }
 __host__ __device__ inline int rec_off_int(int n) { return 36 * n + 32; }
 __host__ __device__ inline int rec_off_rank(int n) { return 36 * n + 56; }
 __host__ __device__ inline int rec_bytes(int n) { return (37 * n + 56 + 15) & ~15; }
+// LDS bytes of one worker wavefront that holds epw environments of n nodes
+__host__ __device__ constexpr int wave_bytes_of(int n, int epw)
+{
+    int wb = epw * ((37 * n + 56 + 15) & ~15);
+    wb += (epw * n * (n + 4) * 4 + 15) & ~15;      // observation tile
+    wb += 2 * epw * (n < 8 ? 8 : n) * 8;          // latencies, energies of the step
+    wb += epw * 8;                                // acting-rank masks
+    wb += 2 * epw * n * 4;                        // load ratios, first arrival per decider
+    return (wb + 15) & ~15;
+}
 enum { I_STEP = 0, I_TASKS, I_VIOL, I_DONE, I_PENDING, I_LOGGED };
 enum { S_TIME = 0, S_ELAPSED, S_SUMLAT, S_SUMEN };
 
@@ -111,7 +121,9 @@ __device__ inline uint64_t group_bits(uint64_t ballot, int g, int gw)
 // (MRRL.PY:806-812): argmin of load/capacity by wavefront shuffles, fixed resource share.
 enum { ACT_DICT = 0, ACT_RAW = 1, ACT_GREEDY = 2 };
 
-template <int LPE, bool TAPE, bool RESET, int ACT>
+// NC: the node count as a compile-time constant (0 = read it from the launch parameters): record offsets, row widths and
+// lane-group arithmetic fold to immediates.  Instantiated for the default topology's n = 10.
+template <int LPE, bool TAPE, bool RESET, int ACT, int NC = 0>
 __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kernel(const EnvParams p, unsigned char* __restrict__ state,
                                                   const EnvConst* __restrict__ cc,
                                                   const int32_t* __restrict__ placement,
@@ -121,17 +133,19 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
 {
     // LPE = 16/32/64: power-of-two lane groups.  LPE = 0: PACKED groups of exactly n lanes (n = 10: six
     // environments per wavefront instead of four); lanes beyond the last whole group idle.  Identical results.
-    const int GW = LPE ? LPE : p.n;      // lanes per environment
+    const int n = NC ? NC : p.n, w = n + 4;
+    const int RB = NC ? rec_bytes(NC) : p.rec_bytes, OF = NC ? NC * (NC + 4) : p.obs_floats;   // record bytes, observation floats
+    const int GW = LPE ? LPE : n;        // lanes per environment
     const int EPW = 64 / GW;             // environments per worker wavefront
+    const int WB = NC ? wave_bytes_of(NC, EPW) : p.wave_bytes;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const int n = p.n, w = n + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_work = (int)(blockDim.x >> 6) - 1;
     const bool scalar_wave = wave == n_work;
     const int64_t env_b0 = (int64_t)blockIdx.x * (n_work * EPW);   // first environment of the workgroup
     const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
-    double* s_win = reinterpret_cast<double*>(smem + n_work * p.wave_bytes);   // [64] window per environment
+    double* s_win = reinterpret_cast<double*>(smem + n_work * WB);   // [64] window per environment
     int32_t* s_nnew = reinterpret_cast<int32_t*>(s_win + 64);                  // [64] arrivals per environment
     // acting-agent totals of the workgroup's environments per 256-environment chunk (out.chunk_totals): two chunks at
     // most (a workgroup holds <= 64 environments), then a count of the worker wavefronts that have added theirs
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     const uint32_t envid = p.env_offset + (uint32_t)env;
 
     // LDS carve-up of a worker wavefront
-    unsigned char* wbase = smem + (scalar_wave ? 0 : wave) * p.wave_bytes;
-    unsigned char* rec = wbase + g * p.rec_bytes;
+    unsigned char* wbase = smem + (scalar_wave ? 0 : wave) * WB;
+    unsigned char* rec = wbase + g * RB;
     double* r_load = reinterpret_cast<double*>(rec);
     double* r_wl = r_load + n;
     double* r_data = r_wl + n;
@@ -161,10 +175,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     int32_t* r_int = reinterpret_cast<int32_t*>(rec + rec_off_int(n));
     int8_t* r_rank = reinterpret_cast<int8_t*>(rec + rec_off_rank(n));
     const int slots = n < 8 ? 8 : n;                   // latency/energy slots per environment (>= 8: batched reads)
-    int off = EPW * p.rec_bytes;
+    int off = EPW * RB;
     float* s_obs_w = reinterpret_cast<float*>(wbase + off);
-    float* s_obs = s_obs_w + g * p.obs_floats;
-    off += (EPW * p.obs_floats * 4 + 15) & ~15;
+    float* s_obs = s_obs_w + g * OF;
+    off += (EPW * OF * 4 + 15) & ~15;
     double* s_lat = reinterpret_cast<double*>(wbase + off) + g * slots;
     off += EPW * slots * 8;
     double* s_en = reinterpret_cast<double*>(wbase + off) + g * slots;
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         const uint32_t eid = p.env_offset + (uint32_t)e;
         double t0 = 0.0;
         if constexpr (!RESET) {
-            if (v) t0 = *reinterpret_cast<const double*>(state + e * p.rec_bytes + rec_off_scal(n) + 8 * S_TIME);
+            if (v) t0 = *reinterpret_cast<const double*>(state + e * RB + rec_off_scal(n) + 8 * S_TIME);
         }
         double rate_u = 0.0, dt_u = 0.0;
         double pu[PRE_POIS_U] = {0.0};     // first uniforms of the Knuth loop, drawn while the clock loads
@@ -289,10 +303,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
             }
         }
         uint4* ldst = reinterpret_cast<uint4*>(wbase);
-        const int nvec = n_valid * p.rec_bytes / 16;
+        const int nvec = n_valid * RB / 16;
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
         if constexpr (!RESET) {
-            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * RB);
             if (lane < nvec) v0 = src[lane];
             if (lane + 64 < nvec) v1 = src[lane + 64];
         }
@@ -335,18 +349,18 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
 
         // ---- stage in: records (zeros at reset), zeroed observation tile, per-step scratch -----------
-        const int nstage = RESET ? EPW * p.rec_bytes / 16 : nvec;
+        const int nstage = RESET ? EPW * RB / 16 : nvec;
         if (lane < nstage) ldst[lane] = v0;
         if (lane + 64 < nstage) ldst[lane + 64] = v1;
         if constexpr (RESET) {
             for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
         } else {
-            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * p.rec_bytes);
+            const uint4* src = reinterpret_cast<const uint4*>(state + env0 * RB);
             for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
         }
         {
             uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
-            for (int i = lane; i < ((EPW * p.obs_floats * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
+            for (int i = lane; i < ((EPW * OF * 4 + 15) >> 4); i += 64) oz[i] = make_uint4(0, 0, 0, 0);
             if (sl == 0) *s_mask = 0ull;
             if (sl < n) s_first[sl] = 0x7fffffff;
         }
@@ -654,10 +668,10 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
     // ---- stage out: records and observation tile, 16-byte lane-linear stores -------------------------
     {
         const uint4* src = reinterpret_cast<const uint4*>(wbase);
-        uint4* dst = reinterpret_cast<uint4*>(state + env0 * p.rec_bytes);
-        for (int i = lane; i < n_valid * p.rec_bytes / 16; i += 64) dst[i] = src[i];
-        const int64_t fbase = env0 * p.obs_floats;
-        const int nfl = n_valid * p.obs_floats;
+        uint4* dst = reinterpret_cast<uint4*>(state + env0 * RB);
+        for (int i = lane; i < n_valid * RB / 16; i += 64) dst[i] = src[i];
+        const int64_t fbase = env0 * OF;
+        const int nfl = n_valid * OF;
         float* gobs = out.obs + fbase;
         if ((fbase & 3) == 0) {
             const float4* s4 = reinterpret_cast<const float4*>(s_obs_w);
@@ -1406,12 +1420,7 @@ EnvParams make_params(const em_handle* h, int lanes)
     p.rec_bytes = rec_bytes(p.n);
     p.obs_floats = p.n * (p.n + 4);
     const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
-    int wb = epw * p.rec_bytes;
-    wb += (epw * p.obs_floats * 4 + 15) & ~15;
-    wb += 2 * epw * (p.n < 8 ? 8 : p.n) * 8;   // latencies, energies of the step
-    wb += epw * 8;                 // acting-rank masks
-    wb += 2 * epw * p.n * 4;       // load ratios, first arrival per decider
-    p.wave_bytes = (wb + 15) & ~15;
+    p.wave_bytes = wave_bytes_of(p.n, epw);
     // _get_current_epsilon, MRRL.PY:249-256 (the several-steps-per-launch kernel re-evaluates it per step)
     double eps = 0.0;
     if (!h->explore_off) {
@@ -1454,6 +1463,16 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     std::memset(&tp, 0, sizeof tp);
     if (tape) tp = *tape;
     const dim3 grid((unsigned)blocks), block(64 * (n_work + 1));
+#define EM_LAUNCH1(L, NC)                                                                                              \
+    do {                                                                                                               \
+        if (lds > 64 * 1024) {                                                                                         \
+            const hipError_t e = hipFuncSetAttribute((const void*)env_kernel<L, TAPE, RESET, ACT, NC>,                 \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                        \
+        }                                                                                                              \
+        hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT, NC>), grid, block, lds, s, p, h->d_state, h->d_const,      \
+                           placement, resource, tp, *out, h->d_lat_log, h->d_err);                                     \
+    } while (0)
 #define EM_LAUNCH(L)                                                                                                   \
     do {                                                                                                               \
         if (k_steps > 1) {                                                                                             \
@@ -1467,13 +1486,11 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
                                    placement, resource, tp, *out, h->d_lat_log, h->d_err);                             \
             }                                                                                                          \
         } else {                                                                                                       \
-            if (lds > 64 * 1024) {                                                                                     \
-                const hipError_t e = hipFuncSetAttribute((const void*)env_kernel<L, TAPE, RESET, ACT>,                \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-                if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                    \
+            if ((L == 0 || L == 16) && p.n == 10) {                                                                    \
+                EM_LAUNCH1(L, 10);                                                                                     \
+            } else {                                                                                                   \
+                EM_LAUNCH1(L, 0);                                                                                      \
             }                                                                                                          \
-            hipLaunchKernelGGL((env_kernel<L, TAPE, RESET, ACT>), grid, block, lds, s, p, h->d_state, h->d_const,     \
-                               placement, resource, tp, *out, h->d_lat_log, h->d_err);                                 \
         }                                                                                                              \
     } while (0)
     if (k_steps > 1 && (TAPE || RESET)) return em::fail(EM_ERR_INVALID, "several steps per launch need the in-kernel random stream");
@@ -1482,6 +1499,7 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
     else if (lanes == 32) EM_LAUNCH(32);
     else EM_LAUNCH(64);
 #undef EM_LAUNCH
+#undef EM_LAUNCH1
     return em::hip_check(hipGetLastError(), "env_kernel launch");
 }
 

@@ -11,7 +11,8 @@ from marl_amd.config import ENV_CONFIG  # noqa: E402
 from marl_amd.env import BatchedEdgeSimGym  # noqa: E402
 
 batches = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 16384, 32768, 65536, 262144]
-for explore in (False, True):
+modes = [bool(int(x)) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [False, True]
+for explore in modes:
     cfg = dict(ENV_CONFIG, disable_env_exploration=not explore)
     for B in batches:
         for lanes in (16, 1):
