@@ -33,7 +33,11 @@
 // -DEM_STAMP); compiled out of the library.
 #ifdef EM_STAMP
 __device__ unsigned long long em_stamps[16];
-#define STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || (threadIdx.x == blockDim.x - 64 && (i) >= 12))) em_stamps[i] = __builtin_readcyclecounter(); } while (0)
+// p.pad0 = i (1..11, tools only): every worker wavefront ends at stamp i, so that a counter run attributes instructions to
+// the program points up to there
+int em_stamp_cut = 0;
+#define STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || (threadIdx.x == blockDim.x - 64 && (i) >= 12))) em_stamps[i] = __builtin_readcyclecounter(); \
+                      if ((i) >= 1 && (i) <= 11 && p.pad0 == (i)) return; } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -89,9 +93,10 @@ struct MultiParams {
 // record has even arrived (lanes 0..7: P_TASK_A, lanes 8..15: P_TASK_B); later arrivals (rare) are drawn
 // inline.  The stream is counter addressed, so this is bit-identical to drawing them one after the other
 // (oracle/edge_oracle.c does that).
-enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512, EM_LANES_PACKED = 1, EM_PACKED_MIN_ENVS = 65536 };
+enum { PAR_TASKS = 8, PRE_POIS_U = 6, EM_ENV_MAX_THREADS = 512, EM_LANES_PACKED = 1, EM_PACKED_MIN_ENVS = 32768 };
 #ifndef EM_ENV_MIN_WAVES
-#define EM_ENV_MIN_WAVES 6     // wavefronts per SIMD the register allocation aims for
+#define EM_ENV_MIN_WAVES 6     // wavefronts per SIMD the register allocation aims for (a 96-register budget for the
+                               // 16-lane kernel removes its 3 spilled registers but costs 13.2 vs 11.1 us at 16,384 environments)
 #endif
 #ifndef EM_ENV_MIN_WAVES_MULTI
 #define EM_ENV_MIN_WAVES_MULTI 4
@@ -304,11 +309,14 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         }
         uint4* ldst = reinterpret_cast<uint4*>(wbase);
         const int nvec = n_valid * RB / 16;
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+        // a third vector per lane only where the wavefront's records are known to need it (it costs four registers)
+        constexpr bool V2 = NC != 0 && (64 / (LPE ? LPE : (NC ? NC : 64))) * ((37 * NC + 56 + 15) & ~15) / 16 > 128;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
         if constexpr (!RESET) {
             const uint4* src = reinterpret_cast<const uint4*>(state + env0 * RB);
             if (lane < nvec) v0 = src[lane];
             if (lane + 64 < nvec) v1 = src[lane + 64];
+            if constexpr (V2) { if (lane + 128 < nvec) v2 = src[lane + 128]; }   // packed, n = 10: 6 records = 162 vectors
         }
 
         // random numbers that depend only on (environment, step, lane): evaluated while the loads fly
@@ -352,11 +360,12 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES) void env_kern
         const int nstage = RESET ? EPW * RB / 16 : nvec;
         if (lane < nstage) ldst[lane] = v0;
         if (lane + 64 < nstage) ldst[lane + 64] = v1;
+        if constexpr (V2) { if (lane + 128 < nstage) ldst[lane + 128] = v2; }
         if constexpr (RESET) {
-            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
+            for (int i = lane + (V2 ? 192 : 128); i < nstage; i += 64) ldst[i] = make_uint4(0, 0, 0, 0);
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(state + env0 * RB);
-            for (int i = lane + 128; i < nstage; i += 64) ldst[i] = src[i];
+            for (int i = lane + (V2 ? 192 : 128); i < nstage; i += 64) ldst[i] = src[i];
         }
         {
             uint4* oz = reinterpret_cast<uint4*>(s_obs_w);
@@ -1405,7 +1414,7 @@ int pick_lanes(int n, int64_t n_envs)
 
 // Wavefronts per workgroup (workers + 1 scalar).  Small batches are bound by the critical path of ONE workgroup, where
 // the workers' barrier wait grows with their number: 4 workers + 1 scalar measured best up to 16,384 environments
-// (6.98 vs 7.43 us per launch at 4,096), 7 + 1 amortises the scalar wavefront best at 65,536 and above.
+// (6.98 vs 7.43 us per launch at 4,096), 7 + 1 amortises the scalar wavefront best from 32,768 (16.4 vs 18.8 us there with the packed layout).
 int pick_waves(int64_t n_envs) { return n_envs < EM_PACKED_MIN_ENVS ? 5 : 8; }
 
 EnvParams make_params(const em_handle* h, int lanes)
@@ -1421,6 +1430,9 @@ EnvParams make_params(const em_handle* h, int lanes)
     p.obs_floats = p.n * (p.n + 4);
     const int epw = 64 / (lanes == EM_LANES_PACKED ? p.n : lanes);
     p.wave_bytes = wave_bytes_of(p.n, epw);
+#ifdef EM_STAMP
+    p.pad0 = em_stamp_cut;
+#endif
     // _get_current_epsilon, MRRL.PY:249-256 (the several-steps-per-launch kernel re-evaluates it per step)
     double eps = 0.0;
     if (!h->explore_off) {
@@ -1486,11 +1498,14 @@ int launch_env(em_handle* h, const int32_t* placement, const float* resource, co
                                    placement, resource, tp, *out, h->d_lat_log, h->d_err);                             \
             }                                                                                                          \
         } else {                                                                                                       \
-            if ((L == 0 || L == 16) && p.n == 10) {                                                                    \
-                EM_LAUNCH1(L, 10);                                                                                     \
-            } else {                                                                                                   \
-                EM_LAUNCH1(L, 0);                                                                                      \
+            bool fixed_n = false;                                                                                      \
+            if constexpr (L == 0 || L == 16) {                                                                         \
+                if (p.n == 10) {                                                                                       \
+                    fixed_n = true;                                                                                    \
+                    EM_LAUNCH1(L, 10);                                                                                 \
+                }                                                                                                      \
             }                                                                                                          \
+            if (!fixed_n) EM_LAUNCH1(L, 0);                                                                            \
         }                                                                                                              \
     } while (0)
     if (k_steps > 1 && (TAPE || RESET)) return em::fail(EM_ERR_INVALID, "several steps per launch need the in-kernel random stream");

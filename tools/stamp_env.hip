@@ -42,6 +42,14 @@ int main(int argc, char** argv)
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 50; ++i) em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
     hipDeviceSynchronize();
+    if (const char* cut = getenv("EM_CUT")) {
+        // counter runs: the warm-up above brought the environments to a typical state; now every worker ends at stamp `cut`
+        em_stamp_cut = atoi(cut);
+        for (int i = 0; i < 1000; ++i) em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
+        hipDeviceSynchronize();
+        printf("cut at stamp %d: 1000 launches\n", em_stamp_cut);
+        return 0;
+    }
     const int K = 500;
     hipEventRecord(e0, nullptr);
     for (int i = 0; i < K; ++i) em_step(h, d_pl, d_rs, nullptr, &out, nullptr);
