@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 5
+#define EM_ABI_VERSION 6
 
 typedef enum em_status {
     EM_OK = 0,
@@ -342,6 +342,17 @@ int em_rollout_index(const em_rollout *ro, int32_t t, const uint64_t *active, co
  * alternately).  No counterpart in the reference. */
 int em_rollout_index_totals(const em_rollout *ro, int32_t t, const uint64_t *active, const int8_t *rank, const float *obs,
                             const uint64_t *chunk_totals, uint64_t *chunk_totals_next, void *stream);
+
+/* em_rollout_index_totals and the actor half of em_policy_step in ONE launch (RolloutBuffer.add + _store_transition +
+ * MAPPO.get_actions + _format_env_actions, mappo_algorithm.py:104-111,189-221, mappo_trainer.py:125-175): each workgroup
+ * numbers and copies the entries of its 256 environments and runs the actor on exactly those entries, reading their
+ * observations from `obs` directly.  Results are bit-identical to the two separate calls.  Needs the states held by
+ * reference (st_state == NULL, obs_tb, st_row), chunk_totals from the step kernel and n_nodes <= 12; the critic is not
+ * evaluated (em_value_all or em_value_step do that).  Arguments as in the two calls it replaces. */
+int em_rollout_policy_step(const em_rollout *ro, int32_t t, const uint64_t *active, const int8_t *rank, const float *obs,
+                           const uint64_t *chunk_totals, uint64_t *chunk_totals_next, const em_mlp3 *actor,
+                           const float *log_std, const float *noise, int explore, uint64_t seed, uint32_t episode,
+                           uint32_t rng_step, uint64_t env_offset, int32_t *placement, float *resource, void *stream);
 
 /* MAPPO.get_actions + MAPPOTrainer._format_env_actions + MAPPO.get_values for step t
  * (mappo_algorithm.py:189-239, mappo_trainer.py:125-158): samples a = mu + sigma*eps for every entry

@@ -14,7 +14,7 @@ from .config import EmConfig, EmmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class EmTape(C.Structure):
@@ -156,6 +156,9 @@ def lib() -> C.CDLL:
     L.em_rollout_index_totals.restype = C.c_int
     L.em_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), vp, C.POINTER(EmMlp3),
                                  C.c_float, C.c_float, vp, i32, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    L.em_rollout_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp, vp, C.POINTER(EmMlp3), vp, vp, i32, u64,
+                                         C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    L.em_rollout_policy_step.restype = C.c_int
     L.em_value_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
     L.em_value_step.restype = C.c_int
     L.em_value_all.argtypes = [C.POINTER(EmRollout), i64, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]

@@ -20,6 +20,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_policy_math.h"
 
 namespace {
 
@@ -65,19 +66,85 @@ __device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
     return make_uint4(c0, c1, c2, c3);
 }
 
-// two standard normals from two 32-bit words (Box-Muller, f32)
-__device__ inline void box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
+enum { P_NOISE = 8 };
+
+// Policy epilogue of one 16-row tile in accumulator layout (y[r] = mean[row c][o = 4q + r]): Gaussian sample + log-prob
+// (mappo_algorithm.py:62-71,209-213) and the trainer's action formatting (mappo_trainer.py:125-158), scattered into the dense
+// environment action arrays.  All 64 lanes of the wavefront must call it (lane shuffles).  `grow`: entry index of the row.
+// ls/sd: log_std[4q + r] and its exponential (policy_scales: once per wavefront, not per tile).
+__device__ __forceinline__ void policy_scales(const FwdArgs& a, const int q, const int O, float (&ls)[4], float (&sd)[4])
 {
-    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.2831853071795865f * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ls[r] = 0.0f; sd[r] = 1.0f;
+        if (a.explore && 4 * q + r < O) { ls[r] = a.log_std[4 * q + r]; sd[r] = expf(ls[r]); }
+    }
 }
 
-enum { P_NOISE = 8 };
+__device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y, const bool valid, const int c_env, const int c_agent,
+                                                const int64_t grow, const int q, const int c, const int O, const float (&ls_)[4],
+                                                const float (&sd_)[4])
+{
+    // ---- policy epilogue ---------------------------------------------------------------------
+    const int n = a.n_nodes;
+    const int env = valid ? c_env : 0;
+    const int agent = valid ? c_agent : 0;
+    float act[4];
+    float lp = 0.0f;
+    float best = -__builtin_inff();
+    int best_i = 1 << 20;
+    bool all_zero = true;
+    uint4 rnd = make_uint4(0, 0, 0, 0);
+    if (a.explore && !a.noise)
+        rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step, (P_NOISE << 24) | ((uint32_t)agent << 4) | (uint32_t)q,
+                      a.seed_lo, a.seed_hi);
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.explore && !a.noise) { em_box_muller(rnd.x, rnd.y, z[0], z[1]); em_box_muller(rnd.z, rnd.w, z[2], z[3]); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * q + r;
+        const bool on = o < O;
+        float v = y[r];
+        if (a.explore && on) {
+            const float ls = ls_[r], sd = sd_[r];
+            const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
+            v = y[r] + e * sd;                                  // rsample, mappo_algorithm.py:65
+            const float d = v - y[r];
+            lp += -(d * d) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f;   // Normal.log_prob
+        }
+        act[r] = v;
+        if (on && o < n) {
+            if (fabsf(v) > 1e-8f) all_zero = false;
+            if (v > best) { best = v; best_i = o; }
+        }
+    }
+    // combine the four lanes (q = 0..3) that share a batch row
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+        lp += __shfl_xor(lp, m);
+        const float ob = __shfl_xor(best, m);
+        const int oi = __shfl_xor(best_i, m);
+        const int oz = __shfl_xor((int)all_zero, m);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+        all_zero = all_zero && (oz != 0);
+    }
+    // resource share from component n (mappo_trainer.py:148-152): tanh in float64, result float32
+    const int src = c + 16 * (n >> 2);
+    const float raw = __shfl(act[0], src) * (float)((n & 3) == 0) + __shfl(act[1], src) * (float)((n & 3) == 1) +
+                      __shfl(act[2], src) * (float)((n & 3) == 2) + __shfl(act[3], src) * (float)((n & 3) == 3);
+    const float share = em_resource_share(raw);
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) a.ent_action[grow * O + 4 * q + r] = act[r];
+        if (q == 0) {
+            a.ent_logp[grow] = a.explore ? lp : 0.0f;          // eval: log_prob = 0 (mappo_algorithm.py:218)
+            const int place = all_zero ? 0 : best_i % n;
+            a.placement[(int64_t)env * n + agent] = place;
+            a.resource[(int64_t)env * n + agent] = share;
+        }
+    }
+}
 
 template <int KU, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
@@ -187,6 +254,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
 
+    float pls[4] = {0.f, 0.f, 0.f, 0.f}, psd[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (MODE == 1) policy_scales(a, q, O, pls, psd);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;          // row relative to row_base
         const bool valid = row < n_rows;
@@ -242,67 +311,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
                 if (a.value_tb) a.value_tb[a.st_env[grow]] = v;
             }
         } else {
-            // ---- policy epilogue ---------------------------------------------------------------------
-            const int n = a.n_nodes;
-            const int env = valid ? c_env : 0;
-            const int agent = valid ? c_agent : 0;
-            float act[4];
-            float lp = 0.0f;
-            float best = -__builtin_inff();
-            int best_i = 1 << 20;
-            bool all_zero = true;
-            uint4 rnd = make_uint4(0, 0, 0, 0);
-            if (a.explore && !a.noise)
-                rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step, (P_NOISE << 24) | ((uint32_t)agent << 4) | (uint32_t)q,
-                              a.seed_lo, a.seed_hi);
-            float z[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.explore && !a.noise) { box_muller(rnd.x, rnd.y, z[0], z[1]); box_muller(rnd.z, rnd.w, z[2], z[3]); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 4 * q + r;
-                const bool on = o < O;
-                float v = y[r];
-                if (a.explore && on) {
-                    const float ls = a.log_std[o];
-                    const float sd = expf(ls);
-                    const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
-                    v = y[r] + e * sd;                                  // rsample, mappo_algorithm.py:65
-                    const float d = v - y[r];
-                    lp += -(d * d) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f;   // Normal.log_prob
-                }
-                act[r] = v;
-                if (on && o < n) {
-                    if (fabsf(v) > 1e-8f) all_zero = false;
-                    if (v > best) { best = v; best_i = o; }
-                }
-            }
-            // combine the four lanes (q = 0..3) that share a batch row
-#pragma unroll
-            for (int m = 16; m <= 32; m <<= 1) {
-                lp += __shfl_xor(lp, m);
-                const float ob = __shfl_xor(best, m);
-                const int oi = __shfl_xor(best_i, m);
-                const int oz = __shfl_xor((int)all_zero, m);
-                if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-                all_zero = all_zero && (oz != 0);
-            }
-            // resource share from component n (mappo_trainer.py:148-152): tanh in float64, result float32
-            const int src = c + 16 * (n >> 2);
-            const float raw = __shfl(act[0], src) * (float)((n & 3) == 0) + __shfl(act[1], src) * (float)((n & 3) == 1) +
-                              __shfl(act[2], src) * (float)((n & 3) == 2) + __shfl(act[3], src) * (float)((n & 3) == 3);
-            if (valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * q + r < O) a.ent_action[grow * O + 4 * q + r] = act[r];
-                if (q == 0) {
-                    a.ent_logp[grow] = a.explore ? lp : 0.0f;          // eval: log_prob = 0 (mappo_algorithm.py:218)
-                    const int place = all_zero ? 0 : best_i % n;
-                    double norm = (tanh((double)raw) + 1.0) / 2.0;
-                    norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
-                    a.placement[(int64_t)env * n + agent] = place;
-                    a.resource[(int64_t)env * n + agent] = (float)(0.1 + 0.9 * norm);
-                }
-            }
+            policy_epilogue(a, y, valid, c_env, c_agent, grow, q, c, O, pls, psd);
         }
     }
 }
@@ -558,6 +567,350 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch per rollout step: rollout_scan_compact_kernel (states by reference) and the policy forward of
+// mlp3_fwd_kernel<1, policy> in ONE kernel.  A workgroup owns a 256-environment chunk: it numbers the chunk's entries,
+// copies the acting agents' rows into the entry storage and then runs the actor on exactly those entries (about 210 per
+// chunk at the default topology: 14 tiles of 16 rows over 8 wavefronts), reading their observations straight from the
+// environment kernel's output through the chunk-local source list that the compaction built in LDS.  The two separate
+// launches cost 10.8 + 17.3 us per step at 65,536 environments plus a kernel boundary; entry order, arithmetic and every
+// stored value are those of the two kernels (same code for the epilogue, same MFMA order), so results are bit-identical.
+// Needs n + 4 <= 16 (one 16-wide input block) and n + 1 <= 16.
+// ------------------------------------------------------------------------------------------------
+#ifdef EM_STAMP_FWD
+__device__ unsigned long long fwd_stamps[16];
+#define FSTAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) fwd_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+struct IndexArgs {
+    int64_t B;
+    int32_t n, t;
+    const uint64_t* active;
+    const int8_t* rank;
+    const float* obs;
+    const unsigned long long* chunk_tot;
+    int32_t n_chunks, pad;
+    uint32_t magic_w, magic_n;   // ceil(2^32 / (n + 4)), ceil(2^32 / n): umulhi(e, magic) == e / d for e < 2^16 (n >= 2)
+    int64_t* counters;
+    uint8_t* k_tb;
+    int32_t* first_tb;
+    int32_t* srow;
+    int64_t cap_e, cap_s;
+    int32_t* err;
+    float* ent_obs;
+    int32_t* ent_env;
+    int8_t* ent_agent;
+    int32_t* st_env;
+    int32_t* st_first;
+    uint8_t* st_k;
+    int32_t* st_row;
+    int64_t row_base;
+    unsigned long long* zero_next;
+};
+
+constexpr int FNT = 512;          // threads of the fused kernel: 8 wavefronts, two per SIMD
+constexpr int FMAXN = 12;         // n + 4 <= 16
+
+// NC: n_nodes as a compile-time constant (0: taken from the arguments); the default topology's n = 10 is instantiated, so
+// that the per-agent loops unroll to exactly n iterations and the index divisions fold.
+template <int NC>
+__global__ __launch_bounds__(FNT, 1) void rollout_policy_kernel(const IndexArgs ia, const FwdArgs a)
+{
+    constexpr int S1 = 18, S2 = 66, HALF = FNT / 2;
+    __shared__ unsigned long long red[2][FNT / 64];
+    __shared__ unsigned long long wave_tot[CHUNK / 64];
+    __shared__ int32_t s_first[CHUNK];
+    __shared__ uint16_t s_list[CHUNK];
+    __shared__ uint8_t s_k[CHUNK];
+    __shared__ uint16_t s_src[CHUNK * FMAXN];   // chunk-local observation row (env * n + agent) of each entry of the chunk
+    __shared__ int s_next;                      // next tile to hand out
+    __shared__ __align__(16) float W1s[HID * S1];
+    __shared__ __align__(16) float W2s[HID * S2];
+    __shared__ __align__(16) float W3s[16 * S2];
+    __shared__ __align__(16) float Bs[2 * HID + 32];     // b1 | b2 | b3 (16) | log_std (16)
+    static_assert(CHUNK == HALF, "the lower half of the workgroup scans one environment per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = NC ? NC : ia.n, t = ia.t;
+    constexpr int NJ = NC ? NC : FMAXN;           // trip count of the per-agent loops
+    const int64_t B = ia.B;
+    const int K1 = NC ? NC + 4 : a.net.in_dim, O = NC ? NC + 1 : a.net.out_dim;
+    FSTAMP(0);
+    if (ia.zero_next) {
+        for (int i = (int)blockIdx.x * FNT + tid; i < ia.n_chunks; i += (int)gridDim.x * FNT) ia.zero_next[i] = 0ull;
+    }
+    const int64_t e_base = ia.counters[4 * t + 0], s_base = ia.counters[4 * t + 2];
+    const int64_t cb = (int64_t)blockIdx.x * CHUNK;
+    // ---- requests that depend on nothing: the chunk's arrival ranks (element j * CHUNK + tid of the chunk's [env][agent]
+    // array: coalesced) and the actor's parameters; the parameters are not waited for until the second barrier
+    // Every load below is UNCONDITIONAL on a clamped address and masked afterwards: a load under a per-lane branch makes the
+    // compiler wait for it where the branch ends, which put three memory round trips in a row in front of the first barrier.
+    int8_t rk[NJ];
+    const int64_t b = cb + tid;
+    const int64_t left = (B - cb) * n;                    // rank elements from the chunk's first to the end of the batch (>= 1)
+    const int lt = tid & (CHUNK - 1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int64_t o_ = (int64_t)j * CHUNK + lt;
+        rk[j] = ia.rank[cb * n + (o_ < left ? o_ : left - 1)];
+    }
+    unsigned long long act_bits = ia.active[b < B ? b : B - 1];
+    unsigned long long tot0 = ia.chunk_tot[tid < ia.n_chunks ? tid : ia.n_chunks - 1];
+    constexpr int N1 = HID * 16 / FNT, N2 = HID * HID / FNT, N3 = 16 * HID / FNT;
+    float v1[N1], v2[N2], v3[N3];
+#pragma unroll
+    for (int j = 0; j < N1; ++j) {
+        const int i = j * FNT + tid, r = i >> 4, kk = i & 15;
+        v1[j] = a.net.w1[r * K1 + (kk < K1 ? kk : K1 - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < N2; ++j) v2[j] = a.net.w2[j * FNT + tid];
+#pragma unroll
+    for (int j = 0; j < N3; ++j) {
+        const int i = j * FNT + tid, r = i >> 6;
+        v3[j] = a.net.w3[(r < O ? r : O - 1) * HID + (i & 63)];
+    }
+    // biases b1 | b2 | b3 (16) | log_std (16): thread tid < 160 fetches element tid of that row
+    const int bsel = tid >> 6, bo = tid & 63, bo16 = (tid & 15) < O ? (tid & 15) : O - 1;
+    const float* bsrc = bsel == 0 ? a.net.b1 + bo : bsel == 1 ? a.net.b2 + bo : (tid & 16) ? a.log_std + bo16 : a.net.b3 + bo16;
+    float vb = *bsrc;
+    // masks
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (!(tid < CHUNK && j < n && (int64_t)j * CHUNK + lt < left)) rk[j] = (int8_t)-1;
+    if (!(tid < CHUNK && b < B)) act_bits = 0ull;
+    if (!(tid < ia.n_chunks)) tot0 = 0ull;
+#pragma unroll
+    for (int j = 0; j < N1; ++j) if (((j * FNT + tid) & 15) >= K1) v1[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N3; ++j) if (((j * FNT + tid) >> 6) >= O) v3[j] = 0.0f;
+    if (tid >= 2 * HID && (tid & 15) >= O) vb = 0.0f;
+
+    // ---- totals of the preceding chunks and of the whole step; scan inside the chunk ----------------------
+    const unsigned long long k = (unsigned long long)__popcll(act_bits);
+    unsigned long long pre = tid < (int)blockIdx.x ? tot0 : 0ull, all = tot0;
+    for (int i = tid + FNT; i < ia.n_chunks; i += FNT) {     // more than 512 chunks (131,072 environments): rare
+        const unsigned long long x = ia.chunk_tot[i];
+        all += x;
+        if (i < (int)blockIdx.x) pre += x;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d); all += __shfl_xor(all, d); }
+    if (lane == 0) { red[0][wave] = pre; red[1][wave] = all; }
+    const unsigned long long v = k | ((k ? 1ull : 0ull) << 32);
+    unsigned long long inc = v;
+    if (wave < CHUNK / 64) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+    }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    FSTAMP(1);
+    pre = 0; all = 0;
+#pragma unroll
+    for (int wv = 0; wv < FNT / 64; ++wv) { pre += red[0][wv]; all += red[1][wv]; }
+    unsigned long long woff = 0, ctot = 0;
+#pragma unroll
+    for (int wv = 0; wv < CHUNK / 64; ++wv) {
+        const unsigned long long x = wave_tot[wv];
+        if (wv < wave) woff += x;
+        ctot += x;
+    }
+    const int64_t ne = (int64_t)(all & 0xffffffffull), ns = (int64_t)(all >> 32);
+    const bool overflow = e_base + ne > ia.cap_e || s_base + ns > ia.cap_s;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (overflow) atomicOr(ia.err, 8);
+        ia.counters[4 * t + 1] = overflow ? 0 : ne;
+        ia.counters[4 * t + 3] = overflow ? 0 : ns;
+        ia.counters[4 * (t + 1) + 0] = e_base + (overflow ? 0 : ne);
+        ia.counters[4 * (t + 1) + 2] = s_base + (overflow ? 0 : ns);
+    }
+    const unsigned long long excl = woff + inc - v;                    // within the chunk
+    const int64_t first = e_base + (int64_t)((pre + excl) & 0xffffffffull);
+    const int64_t sr0 = s_base + (int64_t)(pre >> 32);                 // step row of the chunk's first non-empty env
+    const int li = (int)(excl >> 32);                                  // index among the chunk's non-empty envs
+    if (tid < CHUNK && b < B) {
+        ia.k_tb[b] = (uint8_t)k;
+        ia.first_tb[b] = (int32_t)first;
+        ia.srow[b] = k ? (int32_t)(sr0 + li) : -1;
+    }
+    if (overflow) return;                                              // uniform over the grid: nothing is recorded, nobody acts
+    if (tid < CHUNK) {
+        s_first[tid] = (int32_t)first;
+        s_k[tid] = (uint8_t)k;
+        if (k) s_list[li] = (uint16_t)tid;
+    }
+    // the actor's parameters into LDS (first needed after the third barrier)
+#pragma unroll
+    for (int j = 0; j < N1; ++j) { const int i = j * FNT + tid; W1s[(i >> 4) * S1 + (i & 15)] = v1[j]; }
+#pragma unroll
+    for (int j = 0; j < N2; ++j) { const int i = j * FNT + tid; W2s[(i >> 6) * S2 + (i & 63)] = v2[j]; }
+#pragma unroll
+    for (int j = 0; j < N3; ++j) { const int i = j * FNT + tid; W3s[(i >> 6) * S2 + (i & 63)] = v3[j]; }
+    if (tid < 2 * HID + 32) Bs[tid] = vb;
+    __syncthreads();
+    FSTAMP(2);
+
+    // ---- source row of every entry of the chunk, straight from the rank registers ------------------------------
+    const int n_loc = (int)(ctot >> 32);
+    const int w = n + 4, sw = n * w;
+    // e / w and e / n for e < 2^16: umulhi(e, ceil(2^32 / d))
+    const uint32_t magic_w = NC ? (uint32_t)((0x100000000ull + (NC + 4) - 1) / (NC + 4)) : ia.magic_w;
+    const uint32_t magic_n = NC ? (uint32_t)((0x100000000ull + (NC ? NC : 1) - 1) / (NC ? NC : 1)) : ia.magic_n;
+    const int64_t f0 = e_base + (int64_t)(pre & 0xffffffffull);          // first entry of the chunk
+    const int n_ent = (int)(ctot & 0xffffffffull);
+    if (tid < CHUNK) {
+        int kk[NJ], ff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {                  // all reads first: one LDS round trip, not one per agent
+            const int i = (int)__umulhi((uint32_t)(j * CHUNK + tid), magic_n);
+            kk[j] = j < n ? (int)s_k[i] : 0;
+            ff[j] = j < n ? s_first[i] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = rk[j];
+            if (j < n && r >= 0 && kk[j]) s_src[(int)(ff[j] - f0) + r] = (uint16_t)(j * CHUNK + tid);
+        }
+    }
+    __syncthreads();
+    FSTAMP(3);
+    const float* src0 = ia.obs + cb * sw;
+    if (wave >= CHUNK / 64) {
+        // ---- upper half: the chunk's rows of the entry and step storage.  The lower half is already evaluating the actor;
+        // the half-workgroup offset also keeps the two wavefronts of a SIMD out of step (one's MFMAs under the other's
+        // epilogue arithmetic).
+        const int ht = tid - HALF;
+        const int total = n_ent * w;
+        float* dst0 = ia.ent_obs + f0 * w;
+        constexpr int U = 8;
+        for (int e0 = ht; e0 < total; e0 += HALF * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * HALF;
+                if (e < total) {
+                    const int j = (int)__umulhi((uint32_t)e, magic_w), col = e - j * w;
+                    x[u] = src0[(int)s_src[j] * w + col];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * HALF;
+                if (e < total) dst0[e] = x[u];
+            }
+        }
+        for (int j = ht; j < n_ent; j += HALF) {
+            const int e = (int)s_src[j];
+            const int i = (int)__umulhi((uint32_t)e, magic_n);
+            ia.ent_env[f0 + j] = (int32_t)(cb + i);
+            ia.ent_agent[f0 + j] = (int8_t)(e - i * n);
+        }
+        for (int j = ht; j < n_loc; j += HALF) {
+            const int i = s_list[j];
+            ia.st_env[sr0 + j] = (int32_t)(cb + i);
+            ia.st_first[sr0 + j] = s_first[i];
+            ia.st_k[sr0 + j] = s_k[i];
+            ia.st_row[sr0 + j] = (int32_t)(ia.row_base + cb + i);
+        }
+    }
+    FSTAMP(4);
+
+    // ---- the actor on the chunk's entries: tile = 16 consecutive entries, handed out through a counter -----------
+    const int n_tiles = (n_ent + 15) >> 4;
+    const int q = lane >> 4, c = lane & 15;
+    auto next_tile = [&]() {
+        int tl = 0;
+        if (lane == 0) tl = atomicAdd(&s_next, 1);
+        return __builtin_amdgcn_readfirstlane(tl);
+    };
+    auto load_tile = [&](int tile_, float(&xb_)[4], int& env_, int& agent_) {
+        const int row_ = tile_ * 16 + c;
+        env_ = 0; agent_ = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb_[r] = 0.0f;
+        if (tile_ < n_tiles && row_ < n_ent) {
+            const int e = (int)s_src[row_];
+            const int i = (int)__umulhi((uint32_t)e, magic_n);
+            env_ = (int)(cb + i);
+            agent_ = e - i * n;
+            const float* xr = src0 + e * w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb_[r] = (4 * q + r) < K1 ? xr[4 * q + r] : 0.0f;
+        }
+    };
+    int tile = next_tile();
+    if (tile >= n_tiles) return;
+    float xb[4];
+    int c_env, c_agent;
+    load_tile(tile, xb, c_env, c_agent);
+    float a1[4][4], a2[4][16], a3[16];
+    f32x4 bias1[4], bias2[4], bias3;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[tt][r] = W1s[(16 * tt + c) * S1 + 4 * q + r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a2[tt][s] = W2s[(16 * tt + c) * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];
+        bias1[tt] = *reinterpret_cast<const f32x4*>(Bs + 16 * tt + 4 * q);
+        bias2[tt] = *reinterpret_cast<const f32x4*>(Bs + HID + 16 * tt + 4 * q);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a3[s] = W3s[c * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];
+    bias3 = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 4 * q);
+    float pls[4], psd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                          // policy_scales, with log_std from its LDS copy
+        pls[r] = 0.0f; psd[r] = 1.0f;
+        if (a.explore && 4 * q + r < O) { pls[r] = Bs[2 * HID + 16 + 4 * q + r]; psd[r] = expf(pls[r]); }
+    }
+    FSTAMP(5);
+
+    bool first_tile = true;
+    while (tile < n_tiles) {
+        const int row = tile * 16 + c;
+        const bool valid = row < n_ent;
+        f32x4 h1[4], h2[4], y;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) h1[tt] = bias1[tt];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) h1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt][s], xb[s], h1[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+        const int env = c_env, agent = c_agent;
+        const int nxt = next_tile();                 // the next tile's inputs are requested under this tile's layers 2 and 3
+        load_tile(nxt, xb, c_env, c_agent);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) h2[tt] = bias2[tt];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                h2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][s], h1[s >> 2][s & 3], h2[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[tt][r] = fmaxf(h2[tt][r], 0.0f);
+        y = bias3;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], h2[s >> 2][s & 3], y, 0, 0, 0);
+        if (first_tile) FSTAMP(6);
+        policy_epilogue(a, y, valid, env, agent, f0 + row, q, c, O, pls, psd);
+        if (first_tile) FSTAMP(7);
+        first_tile = false;
+        tile = nxt;
+    }
+    FSTAMP(8);
+}
+
 // Normal(mu, exp(log_std)).log_prob(action).sum(-1) and .entropy().sum(-1) per row (mappo_algorithm.py:43-71): one
 // thread per row, components summed in index order in float32 (torch's sum(dim=-1) over <= 16 components is sequential).
 __global__ __launch_bounds__(256) void gauss_logp_kernel(const float* __restrict__ mu, const float* __restrict__ log_std,
@@ -605,10 +958,8 @@ __global__ __launch_bounds__(256) void format_actions_kernel(const float* __rest
         if (fabsf(v) > 1e-8f) all_zero = false;
         if (v > best) { best = v; best_i = o; }
     }
-    double norm = (tanh((double)a[n]) + 1.0) / 2.0;
-    norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
     placement[r] = all_zero ? 0 : best_i;
-    resource[r] = (float)(0.1 + 0.9 * norm);
+    resource[r] = em_resource_share(a[n]);
 }
 
 int check_net(const em_mlp3* net)
@@ -648,6 +999,10 @@ int launch_fwd(const FwdArgs& fa, int64_t max_rows, hipStream_t s)
 }  // namespace
 
 extern "C" {
+
+#ifdef EM_STAMP_FWD
+int em_debug_fwd_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fwd_stamps), sizeof(unsigned long long) * 16); }
+#endif
 
 int em_mlp3_forward(const em_mlp3* net, const float* x, int64_t ldx, int64_t n_rows, float* y, void* stream)
 {
@@ -747,6 +1102,53 @@ int em_rollout_index_totals(const em_rollout* ro, int32_t t, const uint64_t* act
 {
     if (!chunk_totals) return em::fail(EM_ERR_INVALID, "em_rollout_index_totals: chunk_totals is required");
     return rollout_index_impl(ro, t, active, rank, obs, chunk_totals, chunk_totals_next, stream);
+}
+
+int em_rollout_policy_step(const em_rollout* ro, int32_t t, const uint64_t* active, const int8_t* rank, const float* obs,
+                           const uint64_t* chunk_totals, uint64_t* chunk_totals_next, const em_mlp3* actor, const float* log_std,
+                           const float* noise, int explore, uint64_t seed, uint32_t episode, uint32_t rng_step, uint64_t env_offset,
+                           int32_t* placement, float* resource, void* stream)
+{
+    if (!ro || !active || !rank || !obs || !chunk_totals || !placement || !resource || !log_std)
+        return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: null argument");
+    if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: step %d outside [0,%d)", t, ro->horizon);
+    int rc = check_net(actor);
+    if (rc) return rc;
+    const int n = ro->n_nodes;
+    if (n < 2 || n > FMAXN) return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: n_nodes must be 2..%d (use em_rollout_index_totals + em_policy_step)", FMAXN);
+    if (actor->in_dim != n + 4 || actor->out_dim != n + 1)
+        return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: network shapes do not match n_nodes=%d", n);
+    if (ro->st_state || !ro->obs_tb || !ro->st_row)
+        return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: the rollout must hold its states by reference (obs_tb, st_row)");
+    const int64_t B = ro->n_envs;
+    const int64_t sw = (int64_t)n * (n + 4);
+    const int64_t off = obs - ro->obs_tb;
+    if (off < 0 || off % (B * sw) != 0) return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: obs is not a slice of obs_tb");
+    const int64_t row_base = off / sw;
+    if (row_base + B > 0x7fffffffll) return em::fail(EM_ERR_INVALID, "em_rollout_policy_step: observation history exceeds 2^31 rows");
+    const int64_t chunks = (B + CHUNK - 1) / CHUNK;
+    IndexArgs ia;
+    std::memset(&ia, 0, sizeof ia);
+    ia.B = B; ia.n = n; ia.t = t; ia.active = active; ia.rank = rank; ia.obs = obs;
+    ia.chunk_tot = reinterpret_cast<const unsigned long long*>(chunk_totals); ia.n_chunks = (int)chunks;
+    ia.counters = ro->counters; ia.k_tb = ro->k_tb + (int64_t)t * B; ia.first_tb = ro->first_tb + (int64_t)t * B; ia.srow = ro->srow;
+    ia.cap_e = ro->capacity_entries; ia.cap_s = ro->capacity_steps; ia.err = ro->err_flag;
+    ia.ent_obs = ro->ent_obs; ia.ent_env = ro->ent_env; ia.ent_agent = ro->ent_agent;
+    ia.st_env = ro->st_env; ia.st_first = ro->st_first; ia.st_k = ro->st_k; ia.st_row = ro->st_row; ia.row_base = row_base;
+    ia.zero_next = reinterpret_cast<unsigned long long*>(chunk_totals_next);
+    ia.magic_w = (uint32_t)((0x100000000ull + (uint32_t)(n + 4) - 1u) / (uint32_t)(n + 4));
+    ia.magic_n = (uint32_t)((0x100000000ull + (uint32_t)n - 1u) / (uint32_t)n);
+    FwdArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.net = *actor; fa.ldx = n + 4;
+    fa.log_std = log_std; fa.noise = noise; fa.ent_action = ro->ent_action; fa.ent_logp = ro->ent_logp;
+    fa.ent_env = ro->ent_env; fa.ent_agent = ro->ent_agent; fa.placement = placement; fa.resource = resource;
+    fa.n_nodes = n; fa.explore = explore ? 1 : 0;
+    fa.seed_lo = (uint32_t)seed; fa.seed_hi = (uint32_t)(seed >> 32); fa.episode = episode; fa.step = rng_step;
+    fa.env_offset = (uint32_t)env_offset;
+    if (n == 10) hipLaunchKernelGGL(rollout_policy_kernel<10>, dim3((unsigned)chunks), dim3(FNT), 0, (hipStream_t)stream, ia, fa);
+    else hipLaunchKernelGGL(rollout_policy_kernel<0>, dim3((unsigned)chunks), dim3(FNT), 0, (hipStream_t)stream, ia, fa);
+    return em::hip_check(hipGetLastError(), "rollout_policy_kernel launch");
 }
 
 int em_value_step(const em_rollout* ro, int32_t t, const em_mlp3* critic, float value_norm_mean, float value_norm_var, void* stream)

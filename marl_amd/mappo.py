@@ -410,6 +410,8 @@ class MAPPO:
         # With the states held by reference the critic does not run during the rollout at all: one launch over every
         # recorded state before GAE (em_value_all) replaces a thousand small ones; same rows, same kernel, same bits.
         self.defer_values = True
+        # index/compaction and the actor forward of a step in one launch (em_rollout_policy_step) where the deferred mode applies
+        self.fuse_index_policy = True
         self._values_through = 0          # recorded steps whose values have been computed
 
     def join_value(self):
@@ -447,6 +449,16 @@ class MAPPO:
         with torch.cuda.device(self.device):
             main = torch.cuda.current_stream(self.device)
             s = int(main.cuda_stream)
+            if (totals is not None and self.fuse_index_policy and self._deferred() and 2 <= self.n_agents <= 12):
+                # one launch: entries numbered and copied, actor evaluated on them (bit-identical to the two calls below)
+                _lib.check(L.em_rollout_policy_step(
+                    ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(), totals.data_ptr(),
+                    totals_next.data_ptr() if totals_next is not None else None, a_ref, log_std,
+                    noise.data_ptr() if noise is not None else None, 1 if explore else 0, int(seed) & (2**64 - 1), int(episode),
+                    int(t if rng_step is None else rng_step), int(env_offset), placement_out.data_ptr(), resource_out.data_ptr(),
+                    s), "em_rollout_policy_step")
+                ro.steps_recorded = t + 1
+                return
             if totals is not None:       # the environment kernel already counted the acting agents per chunk
                 _lib.check(L.em_rollout_index_totals(ro.ref, t, active.data_ptr(), rank.data_ptr(), obs.data_ptr(),
                                                      totals.data_ptr(), totals_next.data_ptr() if totals_next is not None else None,

@@ -200,3 +200,60 @@ def test_states_by_reference_equal_compact_copies():
     assert (Ea, Sa) == (Eb, Sb) and Ea > 1000 and oa == ob
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("n_envs,explore", [(700, True), (700, False), (5, True), (4099, True)])
+def test_one_launch_index_and_policy_equals_the_two_launches(n_envs, explore):
+    """em_rollout_policy_step (entries numbered, copied and the actor evaluated on them in one kernel) against
+    em_rollout_index_totals followed by em_policy_step: every stored value, the actions handed to the environment and the
+    update that follows are identical bit for bit (partial chunks, a batch smaller than one tile, evaluation mode)."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.trainer import MAPPOTrainer
+    cfg = dict(ENV_CONFIG, episode_length=40)
+    outs = []
+    for fused in (True, False):
+        tr = MAPPOTrainer(cfg, seed=9, device="cuda:0", n_envs=n_envs, verbose=False)
+        tr.mappo.fuse_index_policy = fused
+        tr.train_episode(explore=explore, record_buffer=True)
+        ro = tr.mappo.buffer
+        E, S = ro.totals()
+        rec = {k: ro.t[k][:E].clone() for k in ("ent_obs", "ent_action", "ent_logp", "ent_env", "ent_agent")}
+        rec.update({k: ro.t[k][:S].clone() for k in ("st_value", "st_env", "st_first", "st_k", "st_row")})
+        rec.update(k_tb=ro.t["k_tb"].clone(), first_tb=ro.t["first_tb"].clone(), reward=ro.t["reward_tb"].clone(),
+                   counters=ro.t["counters"].clone(), obs_tb=ro.t["obs_tb"].clone())
+        out = tr.mappo.update()
+        rec["params"] = tr.mappo.flat_params.clone()
+        outs.append((rec, out, E, S))
+    (a, oa, Ea, Sa), (b, ob, Eb, Sb) = outs
+    assert (Ea, Sa) == (Eb, Sb) and Ea > 0 and oa == ob
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_one_launch_index_and_policy_rejects_what_it_cannot_do():
+    from marl_amd import _lib
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.mappo import RolloutStorage
+    from marl_amd.trainer import MAPPOTrainer
+    import ctypes as C
+    tr = MAPPOTrainer(dict(ENV_CONFIG, episode_length=5), seed=0, device="cuda:0", n_envs=8, verbose=False)
+    m = tr.mappo
+    L = _lib.lib()
+    ro = m.buffer
+    net = m.actor.net()
+    z = torch.zeros(8, 10, dtype=torch.int32, device="cuda")
+    zf = torch.zeros(8, 10, device="cuda")
+    act = torch.zeros(8, dtype=torch.int64, device="cuda")
+    rk = torch.full((8, 10), -1, dtype=torch.int8, device="cuda")
+    tot = ro.chunk_totals[0]
+
+    def call(storage, obs, totals):
+        return L.em_rollout_policy_step(storage.ref, 0, act.data_ptr(), rk.data_ptr(), obs.data_ptr(),
+                                        totals.data_ptr() if totals is not None else None, None, C.byref(net),
+                                        m.actor.log_std.data_ptr(), None, 1, 0, 0, 0, 0, z.data_ptr(), zf.data_ptr(), None)
+    assert call(ro, ro.obs_slice(0), tot) == 0
+    assert call(ro, ro.obs_slice(0), None) != 0                                  # totals are required
+    assert call(ro, torch.zeros(8, 10, 14, device="cuda"), tot) != 0             # not a slice of the history
+    copies = RolloutStorage(8, 10, 5, tr.device, by_reference=False)
+    assert call(copies, torch.zeros(8, 10, 14, device="cuda"), tot) != 0         # states copied: the two-call path
+    assert b"by reference" in L.em_last_error()
