@@ -20,6 +20,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_policy_math.h"
 
 namespace {
 
@@ -39,17 +40,6 @@ __device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
-}
-
-__device__ inline void box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
-{
-    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.2831853071795865f * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
 }
 
 enum { P_NOISE = 8 };
@@ -295,8 +285,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
                     const uint4 rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step,
                                               (P_NOISE << 24) | ((uint32_t)agent << 8) | (uint32_t)(ot << 2) | (uint32_t)q,
                                               a.seed_lo, a.seed_hi);
-                    box_muller(rnd.x, rnd.y, z[0], z[1]);
-                    box_muller(rnd.z, rnd.w, z[2], z[3]);
+                    em_box_muller(rnd.x, rnd.y, z[0], z[1]);
+                    em_box_muller(rnd.z, rnd.w, z[2], z[3]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -332,11 +322,9 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
             if (valid && q == 0) {
                 a.ent_logp[grow] = a.explore ? lp : 0.0f;                  // eval: log_prob = 0 (mappo_algorithm.py:218)
                 const int place = all_zero ? 0 : best_i % n;
-                double norm = (tanh((double)res_raw) + 1.0) / 2.0;        // mappo_trainer.py:148-152
-                norm = norm < 0.0 ? 0.0 : (norm > 1.0 ? 1.0 : norm);
                 const int64_t dst = a.ent_dst[grow];
                 a.placement[dst] = place;
-                a.resource[dst] = (float)(0.1 + 0.9 * norm);
+                a.resource[dst] = em_resource_share(res_raw);             // mappo_trainer.py:148-152
             }
         }
     }
