@@ -515,6 +515,15 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         }
 
         // ---- backward through layer 3 and 2 ----------------------------------------------------------
+        // The weight-gradient products below need their operands with the batch index on the reduction axis: one
+        // 64 x 16 transpose per operand through the per-wavefront LDS scratch.  Done where they are needed, each transpose
+        // is an exposed LDS round trip (write, read, wait) in front of an MFMA block, 5.5 of them per tile with one or two
+        // wavefronts per SIMD.  Here the LDS instructions of a transpose are issued BETWEEN the MFMA batches of the block
+        // before the one that consumes it, as soon as the source registers hold their final value:
+        //   dY, H2 (for dW3)  under the 64 MFMAs of dZ1;   dZ2 (for dW2)  under the 16 MFMAs of dW3;
+        //   dZ1 (for dW1)     under the 64 MFMAs of dW2.   Only H1 (for dW2) is still transposed in the open.
+        // One scratch area is enough: the LDS executes a wavefront's instructions in order, so a later write cannot
+        // overtake an earlier read.  The transposed copies take the registers their sources free (no higher peak).
         gb3 += dy;
         f32x4 dz2[4], dz1[4];
 #pragma unroll
@@ -536,6 +545,17 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) dz1[t] = zero4;
+        // transposed fragments: tr[t][s] = X[feature 16t + c][batch 4s + q]
+        float tr_y[4], tr_a[4][4], tr_b[4][4], tr_c[4][4];
+        float* const wcol = scr + 4 * q * TS + c;      // element (feature 16t + 4q + r, batch c) goes to wcol[(16t + r) * TS]
+        const float* const rrow = scr + c * TS + q;    // tr[t][s] comes from rrow[16t * TS + 4s]
+        const float* const rsum = scr + lane * TS;     // row `lane` of a transposed tile: feature `lane` over the 16 batch rows
+        auto opB = [&](int i) {                         // 40 LDS instructions: dY and H2 out, tr_y and tr_b (for dW3) back
+            if (i < 4) wcol[i * TS] = dy[i];
+            else if (i < 8) tr_y[i - 4] = rrow[4 * (i - 4)];
+            else if (i < 24) wcol[(16 * ((i - 8) >> 2) + ((i - 8) & 3)) * TS] = h2[(i - 8) >> 2][(i - 8) & 3];
+            else tr_b[(i - 24) >> 2][(i - 24) & 3] = rrow[16 * ((i - 24) >> 2) * TS + 4 * ((i - 24) & 3)];
+        };
 #pragma unroll
         for (int u = 0; u < 4; ++u) {      // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
 #pragma unroll
@@ -549,10 +569,11 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) ldW2T(u + 1, t, h, aw[t]);
                 }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) opB(5 * (2 * u + h) + i);
                 EM_SB();
             }
         }
-#undef EM_SB
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -560,56 +581,71 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         }
 
         // ---- weight gradients: reduction over the 16 batch rows of the tile ---------------------------
-        // transposed fragments: trX[t][s] = X[feature 16t + c][batch 4s + q]
-        float tr_a[4][4], tr_b[4][4];
-        // rowsum: += sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
-        auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4], float* rowsum) {
+        // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]; dZ2 leaves for the scratch between its MFMAs
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = m[t][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) out[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
-            if (rowsum) {
-                float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 16; j += 2) { p0 += scr[lane * TS + j]; p1 += scr[lane * TS + j + 1]; }
-                *rowsum += p0 + p1;
+            for (int t = 0; t < 4; ++t) {
+                gW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[t], 0, 0, 0);
+                wcol[(16 * s + t) * TS] = dz2[s][t];
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        };
-        // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
-        float tr_y[4];
+            EM_SB();
+        }
+        // rowsum: sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
+        auto row_sum = [&](float& acc) {
+            float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scr[(4 * q + r) * TS + c] = dy[r];
+            for (int j = 0; j < 16; j += 2) { p0 += rsum[j]; p1 += rsum[j + 1]; }
+            acc += p0 + p1;
+        };
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) tr_y[s] = scr[c * TS + 4 * s + q];
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tr_a[t][s] = rrow[16 * t * TS + 4 * s];
+        row_sum(gb2_l);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        transpose64(h2, tr_b, nullptr);
+        // H1 (its last use above was the ReLU mask of dZ1)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) gW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[t], 0, 0, 0);
-        // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
-        transpose64(dz2, tr_a, &gb2_l);
-        transpose64(h1, tr_b, nullptr);
+            for (int r = 0; r < 4; ++r) wcol[(16 * t + r) * TS] = h1[t][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2)
+            for (int s = 0; s < 4; ++s) tr_b[t][s] = rrow[16 * t * TS + 4 * s];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]; dZ1 is transposed (and row-summed: gb1) between the batches
+        float pb0 = 0.0f, pb1 = 0.0f;
+        auto opC = [&](int i) {                         // 48 LDS instructions: dZ1 out, tr_c back, 16 row-sum reads
+            if (i < 16) wcol[(16 * (i >> 2) + (i & 3)) * TS] = dz1[i >> 2][i & 3];
+            else if (i < 32) tr_c[(i - 16) >> 2][(i - 16) & 3] = rrow[16 * ((i - 16) >> 2) * TS + 4 * ((i - 16) & 3)];
+            else if ((i & 1) == 0) pb0 += rsum[i - 32];
+            else pb1 += rsum[i - 32];
+        };
 #pragma unroll
-                for (int t1 = 0; t1 < 4; ++t1)
-                    gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int t2 = 2 * hh; t2 < 2 * hh + 2; ++t2)
+#pragma unroll
+                    for (int t1 = 0; t1 < 4; ++t1)
+                        gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+                EM_SB();
+#pragma unroll
+                for (int i = 0; i < 6; ++i) opC(6 * (2 * s + hh) + i);
+                EM_SB();
+            }
+        }
+        gb1_l += pb0 + pb1;
+#undef EM_SB
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
-        transpose64(dz1, tr_a, &gb1_l);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
@@ -622,7 +658,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                 else xv = (rb < a.n_rows && i < K1) ? xrow[i] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
+                    gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_c[t][s], xv, gW1[t][u], 0, 0, 0);
             }
         }
         if constexpr (STAGE) {                        // the next tile has landed; this tile's half may be overwritten
