@@ -1305,6 +1305,106 @@ __global__ __launch_bounds__(EM_ENV_MAX_THREADS, EM_ENV_MIN_WAVES_MULTI) void en
 // ------------------------------------------------------------------------------------------------
 // episode metrics (MRRL.PY:470-504); p99 from the latency log when present
 // ------------------------------------------------------------------------------------------------
+// the five metrics that need no sort, and the p99 handed in (MRRL.PY:470-504); one thread per environment calls it
+__device__ inline void write_metrics(const EnvParams& p, const EnvConst* __restrict__ cc, const double* scal, const int32_t* ri,
+                                     double p99, double* __restrict__ o)
+{
+    const int n = p.n;
+    const int tasks = ri[I_TASKS];
+    const double cnt = (double)(tasks ? tasks : 1);
+    o[0] = tasks ? scal[S_SUMLAT] * 1000 / (double)tasks : 0.0;
+    o[1] = p99;
+    o[2] = tasks ? scal[S_SUMEN] / (double)tasks : __builtin_nan("");
+    o[3] = (double)ri[I_VIOL] / cnt;
+    const double el = scal[S_ELAPSED];
+    o[4] = (double)ri[I_DONE] / (el > 1e-6 ? el : 1e-6);
+    // Jain index over per-node mean cpu usage; usage sample of a step = cap*dt/(cap+1e-9)
+    // (MRRL.PY:379-381), reset contributes one zero sample (MRRL.PY:367-368,381).
+    const double samples = (double)(ri[I_STEP] + 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double m_i = (cc->cap[i] * el / (cc->cap[i] + 1e-9)) / samples;
+        s1 += m_i;
+        s2 += m_i * m_i;
+    }
+    o[5] = (s1 * s1) / ((double)n * s2 + 1e-9);
+}
+
+// np.percentile(x, 99) ('linear' method) from the two order statistics it interpolates: a = sorted[lo], b = sorted[hi]
+__device__ inline void p99_indices(int logged, int& lo, int& hi, double& t)
+{
+    const double vi = (double)(logged - 1) * (99.0 / 100.0);
+    const double fl = floor(vi);
+    lo = (int)fl; hi = lo + 1;
+    if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
+    if (hi > logged - 1) hi = logged - 1;
+    t = vi - fl;
+}
+__device__ inline double p99_lerp(double a, double b, double t)
+{
+    const double d = b - a;
+    return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
+}
+
+// The p99 needs sorted[lo] and sorted[hi] with lo = floor(0.99 (L - 1)): the (L - lo)-th largest value and its neighbour,
+// about 1 % of the log from the top.  One WAVEFRONT per environment holds the log in registers (SEL_PER_LANE values per
+// lane) and extracts maxima one at a time (lane-local maximum, wavefront maximum by shuffles, the lowest owning lane drops
+// one copy): a dozen rounds for the default episode's ~830 tasks, where the full bitonic sort of metrics_kernel takes 55
+// workgroup barriers.  Same two order statistics, same interpolation: identical results.
+constexpr int SEL_PER_LANE = 32;                 // logs up to 2,048 tasks; larger ones take metrics_kernel
+constexpr int SEL_MAX_ROUNDS = 64;
+__global__ __launch_bounds__(256) void metrics_select_kernel(const EnvParams p, const unsigned char* __restrict__ state,
+                                                             const EnvConst* __restrict__ cc,
+                                                             const double* __restrict__ lat_log, double* __restrict__ out6)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= p.n_envs) return;
+    const int n = p.n;
+    const unsigned char* rec = state + env * p.rec_bytes;
+    const double* scal = reinterpret_cast<const double*>(rec + rec_off_scal(n));
+    const int32_t* ri = reinterpret_cast<const int32_t*>(rec + rec_off_int(n));
+    const int tasks = ri[I_TASKS];
+    const int logged = ri[I_LOGGED];
+    double p99 = __builtin_nan("");
+    if (tasks == 0) p99 = 0.0;
+    else if (logged == tasks) {
+        int lo, hi;
+        double t;
+        p99_indices(logged, lo, hi, t);
+        const int k_lo = logged - 1 - lo, k_hi = logged - 1 - hi;      // ranks from the top (0 = maximum), k_hi <= k_lo
+        // k_lo <= 0.01 L + 1 <= 22 for the L <= 2,048 that the host sends here: the guard cannot trigger (NaN if it did)
+        if (k_lo < SEL_MAX_ROUNDS && logged <= 64 * SEL_PER_LANE) {
+            double v[SEL_PER_LANE];
+#pragma unroll
+            for (int j = 0; j < SEL_PER_LANE; ++j) {
+                const int i = j * 64 + lane;
+                v[j] = i < logged ? lat_log[env * p.lat_cap + i] * 1000 : -__builtin_inf();
+            }
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r <= k_lo; ++r) {
+                double m = v[0];
+#pragma unroll
+                for (int j = 1; j < SEL_PER_LANE; ++j) m = v[j] > m ? v[j] : m;
+                double w = m;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(w, d); w = o > w ? o : w; }
+                if (r == k_hi) b = w;
+                if (r == k_lo) a = w;
+                const unsigned long long own = __ballot(m == w);
+                if (lane == __ffsll(own) - 1) {                        // drop ONE copy of the maximum
+                    bool gone = false;
+#pragma unroll
+                    for (int j = 0; j < SEL_PER_LANE; ++j)
+                        if (!gone && v[j] == w) { v[j] = -__builtin_inf(); gone = true; }
+                }
+            }
+            p99 = p99_lerp(a, b, t);
+        }
+    }
+    if (lane == 0) write_metrics(p, cc, scal, ri, p99, out6 + env * 6);
+}
+
 __global__ __launch_bounds__(256) void metrics_kernel(const EnvParams p, const unsigned char* __restrict__ state,
                                                       const EnvConst* __restrict__ cc,
                                                       const double* __restrict__ lat_log, double* __restrict__ scratch,
@@ -1342,35 +1442,13 @@ __global__ __launch_bounds__(256) void metrics_kernel(const EnvParams p, const u
             }
         }
         if (threadIdx.x == 0) {
-            const double vi = (double)(logged - 1) * (99.0 / 100.0);   // numpy 'linear' method
-            const double fl = floor(vi);
-            int lo = (int)fl, hi = lo + 1;
-            if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
-            if (hi > logged - 1) hi = logged - 1;
-            const double a = buf[lo], b = buf[hi], t = vi - fl, d = b - a;
-            p99 = (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
+            int lo, hi;
+            double t;
+            p99_indices(logged, lo, hi, t);                            // numpy 'linear' method
+            p99 = p99_lerp(buf[lo], buf[hi], t);
         }
     }
-    if (threadIdx.x == 0) {
-        double* o = out6 + env * 6;
-        const double cnt = (double)(tasks ? tasks : 1);
-        o[0] = tasks ? scal[S_SUMLAT] * 1000 / (double)tasks : 0.0;
-        o[1] = p99;
-        o[2] = tasks ? scal[S_SUMEN] / (double)tasks : __builtin_nan("");
-        o[3] = (double)ri[I_VIOL] / cnt;
-        const double el = scal[S_ELAPSED];
-        o[4] = (double)ri[I_DONE] / (el > 1e-6 ? el : 1e-6);
-        // Jain index over per-node mean cpu usage; usage sample of a step = cap*dt/(cap+1e-9)
-        // (MRRL.PY:379-381), reset contributes one zero sample (MRRL.PY:367-368,381).
-        const double samples = (double)(ri[I_STEP] + 1);
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = 0; i < n; ++i) {
-            const double m_i = (cc->cap[i] * el / (cc->cap[i] + 1e-9)) / samples;
-            s1 += m_i;
-            s2 += m_i * m_i;
-        }
-        o[5] = (s1 * s1) / ((double)n * s2 + 1e-9);
-    }
+    if (threadIdx.x == 0) write_metrics(p, cc, scal, ri, p99, out6 + env * 6);
 }
 
 }  // namespace
@@ -1714,13 +1792,19 @@ int em_episode_metrics(em_handle* h, double* out6, void* stream)
 {
     if (!h || !out6) return em::fail(EM_ERR_INVALID, "em_episode_metrics: null argument");
     const EnvParams p = make_params(h, h->lanes);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->d_lat_log && h->lat_cap <= 64 * SEL_PER_LANE) {
+        hipLaunchKernelGGL(metrics_select_kernel, dim3((unsigned)((h->n_envs + 3) / 4)), dim3(256), 0, s, p, h->d_state, h->d_const,
+                           h->d_lat_log, out6);
+        return em::hip_check(hipGetLastError(), "metrics_select_kernel launch");
+    }
     int64_t m = 1;
     while (m < h->lat_cap) m <<= 1;
     size_t lds = h->d_lat_log ? (size_t)m * 8 : 16;
     if (lds > 128 * 1024) lds = 16;
     if (lds > 64 * 1024)
         EM_HIP(hipFuncSetAttribute((const void*)metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, (hipStream_t)stream, p, h->d_state,
+    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, s, p, h->d_state,
                        h->d_const, h->d_lat_log, h->d_sort_scratch, out6);
     return em::hip_check(hipGetLastError(), "metrics_kernel launch");
 }

@@ -68,6 +68,13 @@ __device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
 
 enum { P_NOISE = 8 };
 
+#ifdef EM_STAMP_FWD
+__device__ unsigned long long fwd_stamps[16];
+#define FSTAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) fwd_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
 // Policy epilogue of one 16-row tile in accumulator layout (y[r] = mean[row c][o = 4q + r]): Gaussian sample + log-prob
 // (mappo_algorithm.py:62-71,209-213) and the trainer's action formatting (mappo_trainer.py:125-158), scattered into the dense
 // environment action arrays.  All 64 lanes of the wavefront must call it (lane shuffles).  `grow`: entry index of the row.
@@ -98,8 +105,10 @@ __device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y,
     if (a.explore && !a.noise)
         rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step, (P_NOISE << 24) | ((uint32_t)agent << 4) | (uint32_t)q,
                       a.seed_lo, a.seed_hi);
+    FSTAMP(9);
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.explore && !a.noise) { em_box_muller(rnd.x, rnd.y, z[0], z[1]); em_box_muller(rnd.z, rnd.w, z[2], z[3]); }
+    FSTAMP(10);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 4 * q + r;
@@ -118,6 +127,7 @@ __device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y,
             if (v > best) { best = v; best_i = o; }
         }
     }
+    FSTAMP(11);
     // combine the four lanes (q = 0..3) that share a batch row
 #pragma unroll
     for (int m = 16; m <= 32; m <<= 1) {
@@ -128,11 +138,13 @@ __device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y,
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         all_zero = all_zero && (oz != 0);
     }
+    FSTAMP(12);
     // resource share from component n (mappo_trainer.py:148-152): tanh in float64, result float32
     const int src = c + 16 * (n >> 2);
     const float raw = __shfl(act[0], src) * (float)((n & 3) == 0) + __shfl(act[1], src) * (float)((n & 3) == 1) +
                       __shfl(act[2], src) * (float)((n & 3) == 2) + __shfl(act[3], src) * (float)((n & 3) == 3);
     const float share = em_resource_share(raw);
+    FSTAMP(13);
     if (valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -577,12 +589,6 @@ __global__ __launch_bounds__(CHUNK) void rollout_scan_compact_kernel(
 // stored value are those of the two kernels (same code for the epilogue, same MFMA order), so results are bit-identical.
 // Needs n + 4 <= 16 (one 16-wide input block) and n + 1 <= 16.
 // ------------------------------------------------------------------------------------------------
-#ifdef EM_STAMP_FWD
-__device__ unsigned long long fwd_stamps[16];
-#define FSTAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) fwd_stamps[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#endif
 struct IndexArgs {
     int64_t B;
     int32_t n, t;

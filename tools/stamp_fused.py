@@ -24,6 +24,7 @@ for _ in range(R):
     assert L.em_debug_fwd_stamps(st) == 0
     for i in range(8):
         acc[i] += (st[i + 1] - st[i]) / R
+print('  epilogue (last tile): box-muller %d, sample+logp %d, shuffles %d, share %d' % tuple((st[i+1]-st[i]) for i in range(9,13)))
 tot = 0
 for n_, v in zip(names, acc):
     print(f"  {n_:50s} {v:9.0f} cycles")
