@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void scaled_chain_kernel(const ScaledParams p,
 // The step of ONE environment on one wavefront (servers, pending slots and arrivals on lanes).  Used by
 // scaled_env_kernel (one wavefront per environment) and as the general path of scaled_env4_kernel for environments whose
 // step has more than 16 pending slots or arrivals.  window / n_new: this step's row of the scalar chain.
-template <bool RESET>
+// SC / DC: server and decider counts as compile-time constants (0: taken from the launch parameters); instantiated for
+// BASELINE.json configs[4] (64 servers, 256 deciders) so that record offsets, row widths and loop bounds fold.
+template <bool RESET, int SC = 0, int DC = 0>
 __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned char* __restrict__ state, const EnvConst* __restrict__ cc,
                                              const int32_t* __restrict__ placement, const float* __restrict__ resource,
                                              const double window, const int n_new, const ems_step_out& out,
@@ -170,10 +172,11 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
                                              const int lane, double* s_load, double* s_lat, double* s_en, int32_t* s_queue,
                                              float* s_ratio, int32_t* s_pdec)
 {
-    const int S = p.S, D = p.D, w = S + 4;
+    const int S = SC ? SC : p.S, D = DC ? DC : p.D, w = S + 4;
+    const int RB = SC ? srec_bytes(SC) : p.rec_bytes;
     const uint32_t eid = p.env_offset + (uint32_t)env;
     const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
-    unsigned char* rec = state + env * (int64_t)p.rec_bytes;
+    unsigned char* rec = state + env * (int64_t)RB;
     double* g_load = reinterpret_cast<double*>(rec);
     int32_t* g_queue = reinterpret_cast<int32_t*>(rec + srec_off_queue(S));
     double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
@@ -469,7 +472,7 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
 
 // One wavefront per environment; a workgroup is WAVES_PER_BLOCK independent wavefronts (no workgroup barrier).
 // chain_win / chain_n: this step's row of the scalar chain (scaled_chain_kernel).
-template <bool RESET>
+template <bool RESET, int SC = 0, int DC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES) void scaled_env_kernel(const ScaledParams p, unsigned char* __restrict__ state,
                                                                         const EnvConst* __restrict__ cc,
                                                                         const int32_t* __restrict__ placement,
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES) void scaled_en
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t env = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (env >= p.n_envs) return;                 // whole wavefronts leave; nothing below synchronises across wavefronts
-    step_one_env<RESET>(p, state, cc, placement, resource, chain_win[env], chain_n[env], out, lat_log, err_flag, env, lane,
+    step_one_env<RESET, SC, DC>(p, state, cc, placement, resource, chain_win[env], chain_n[env], out, lat_log, err_flag, env, lane,
                         s_load_all[wave], s_lat_all[wave], s_en_all[wave], s_queue_all[wave], s_ratio_all[wave], s_pdec_all[wave]);
 }
 
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES) void scaled_en
 // reset) takes step_one_env on the whole wavefront afterwards.  Bit-identical to scaled_env_kernel.
 constexpr int EPW4 = 4, GW4 = 16;
 
-template <bool RESET>
+template <bool RESET, int SC = 0, int DC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_env4_kernel(const ScaledParams p, unsigned char* __restrict__ state,
                                                                          const EnvConst* __restrict__ cc,
                                                                          const int32_t* __restrict__ placement,
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     __shared__ double s_cap[64], s_icap[64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = p.S, D = p.D, w = S + 4;
+    const int S = SC ? SC : p.S, D = DC ? DC : p.D, w = S + 4;
+    const int RB = SC ? srec_bytes(SC) : p.rec_bytes;
     if (threadIdx.x < 64) {
         s_cap[threadIdx.x] = (int)threadIdx.x < S ? cc->cap[threadIdx.x] : 1.0;
         s_icap[threadIdx.x] = (int)threadIdx.x < S ? cc->inv_cap[threadIdx.x] : 1.0;
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     const uint32_t eid = p.env_offset + (uint32_t)env;
     const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
     const int64_t renv = valid ? env : env0;     // lanes of an absent environment shadow the first one and never store
-    unsigned char* rec = state + renv * (int64_t)p.rec_bytes;
+    unsigned char* rec = state + renv * (int64_t)RB;
     double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
     int32_t* g_int = reinterpret_cast<int32_t*>(rec + srec_off_int(S));
     double* g_pwl = reinterpret_cast<double*>(rec + srec_off_pend(S));
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         srv_q[e] = 0;
         if constexpr (!RESET) {
             if (env0 + e < p.n_envs && lane < S) {
-                const unsigned char* r = state + (env0 + e) * (int64_t)p.rec_bytes;
+                const unsigned char* r = state + (env0 + e) * (int64_t)RB;
                 srv_l[e] = reinterpret_cast<const double*>(r)[lane];
                 srv_q[e] = reinterpret_cast<const int32_t*>(r + srec_off_queue(S))[lane];
             }
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
                 q = q - 1 > 0 ? q - 1 : 0;
             }
             if (lane < S) {
-                unsigned char* r = state + (env0 + e) * (int64_t)p.rec_bytes;
+                unsigned char* r = state + (env0 + e) * (int64_t)RB;
                 reinterpret_cast<double*>(r)[lane] = l;
                 reinterpret_cast<int32_t*>(r + srec_off_queue(S))[lane] = q;
             }
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
             sb &= sb - 1ull;
             const double win_e = rl_d(window, 16 * e);
             const int nn_e = rl_i(n_new, 16 * e);
-            step_one_env<RESET>(p, state, cc, placement, resource, win_e, nn_e, out, lat_log, err_flag, env0 + e, lane, s_load[0],
+            step_one_env<RESET, SC, DC>(p, state, cc, placement, resource, win_e, nn_e, out, lat_log, err_flag, env0 + e, lane, s_load[0],
                                 s_lat, s_en, s_queue[0], s_ratio[0], s_pdec_all[wave]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1083,14 +1087,25 @@ int ems_reset(ems_handle* h, int has_seed, uint64_t seed, const ems_step_out* ou
     if (crc) return crc;
     const int64_t per_block = (int64_t)WAVES_PER_BLOCK * h->envs_per_wave;
     const dim3 grid((unsigned)((h->n_envs + per_block - 1) / per_block)), block(64 * WAVES_PER_BLOCK);
-    if (h->envs_per_wave == 4)
-        hipLaunchKernelGGL((scaled_env4_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
-                           nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
-                           h->d_lat_log, h->d_err);
-    else
-        hipLaunchKernelGGL((scaled_env_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
-                           nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
-                           h->d_lat_log, h->d_err);
+    if (h->envs_per_wave == 4) {
+        if (p.S == 64 && p.D == 256)
+            hipLaunchKernelGGL((scaled_env4_kernel<true, 64, 256>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
+                               nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+        else
+            hipLaunchKernelGGL((scaled_env4_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
+                               nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+    } else {
+        if (p.S == 64 && p.D == 256)
+            hipLaunchKernelGGL((scaled_env_kernel<true, 64, 256>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
+                               nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+        else
+            hipLaunchKernelGGL((scaled_env_kernel<true>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, nullptr,
+                               nullptr, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+    }
     return em::hip_check(hipGetLastError(), "scaled_env_kernel<reset> launch");
 }
 
@@ -1109,14 +1124,25 @@ int ems_step(ems_handle* h, const int32_t* placement, const float* resource, int
     if (crc) return crc;
     const int64_t per_block = (int64_t)WAVES_PER_BLOCK * h->envs_per_wave;
     const dim3 grid((unsigned)((h->n_envs + per_block - 1) / per_block)), block(64 * WAVES_PER_BLOCK);
-    if (h->envs_per_wave == 4)
-        hipLaunchKernelGGL((scaled_env4_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
-                           resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
-                           h->d_lat_log, h->d_err);
-    else
-        hipLaunchKernelGGL((scaled_env_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
-                           resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
-                           h->d_lat_log, h->d_err);
+    if (h->envs_per_wave == 4) {
+        if (p.S == 64 && p.D == 256)
+            hipLaunchKernelGGL((scaled_env4_kernel<false, 64, 256>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
+                               resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+        else
+            hipLaunchKernelGGL((scaled_env4_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
+                               resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+    } else {
+        if (p.S == 64 && p.D == 256)
+            hipLaunchKernelGGL((scaled_env_kernel<false, 64, 256>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
+                               resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+        else
+            hipLaunchKernelGGL((scaled_env_kernel<false>), grid, block, 0, (hipStream_t)stream, p, h->d_state, h->d_const, placement,
+                               resource, h->d_chain_win + (int64_t)row * h->n_envs, h->d_chain_n + (int64_t)row * h->n_envs, *out,
+                               h->d_lat_log, h->d_err);
+    }
     const int lrc = em::hip_check(hipGetLastError(), "scaled_env_kernel<step> launch");
     if (lrc) return lrc;
     h->step += 1;
