@@ -190,7 +190,8 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
                                         "32,384, critic 60,800 per row and epoch) over the update's whole wall time (GAE, "
                                         "reductions, Adam included); mfma_issue_frac: time the issued MFMA instructions need "
                                         "at 2.4 GHz over the same wall time; survey_convention_frac: 3 x forward FLOPs"},
-            "rollout": "states by reference, acting-agent totals from the step kernel, one critic launch per episode",
+            "rollout": "two launches per step (env step; entry numbering + copy + actor in one kernel), states by reference, "
+                       "acting-agent totals from the step kernel, one critic launch per episode (inside rollout_s)",
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 

@@ -24,9 +24,9 @@ def signature(names):
 
 
 KERNELS = {   # key in traffic.json -> (kernel-name needle, sources whose hash pins the figure)
-    "4096": ("env_kernel<16, false, false, 0>", ("edge_env.hip", "em_env_math.h", "em_common.h")),
-    "65536": ("env_kernel<0, false, false, 0>", ("edge_env.hip", "em_env_math.h", "em_common.h")),
-    "scaled_env4_kernel@65536": ("scaled_env4_kernel<false>", ("edge_env_scaled.hip", "em_env_math.h", "em_common.h")),
+    "4096": ("env_kernel<16, false, false, 0, 10>", ("edge_env.hip", "em_env_math.h", "em_common.h")),
+    "65536": ("env_kernel<0, false, false, 0, 10>", ("edge_env.hip", "em_env_math.h", "em_common.h")),
+    "scaled_env4_kernel@65536": ("scaled_env4_kernel<false, 64, 256>", ("edge_env_scaled.hip", "em_env_math.h", "em_common.h")),
     "marl_env_kernel@65536": ("marl_env_kernel<false>", ("edge_marl_env.hip", "em_env_math.h", "em_common.h")),
 }
 
