@@ -1330,29 +1330,11 @@ __device__ inline void write_metrics(const EnvParams& p, const EnvConst* __restr
     o[5] = (s1 * s1) / ((double)n * s2 + 1e-9);
 }
 
-// np.percentile(x, 99) ('linear' method) from the two order statistics it interpolates: a = sorted[lo], b = sorted[hi]
-__device__ inline void p99_indices(int logged, int& lo, int& hi, double& t)
-{
-    const double vi = (double)(logged - 1) * (99.0 / 100.0);
-    const double fl = floor(vi);
-    lo = (int)fl; hi = lo + 1;
-    if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
-    if (hi > logged - 1) hi = logged - 1;
-    t = vi - fl;
-}
-__device__ inline double p99_lerp(double a, double b, double t)
-{
-    const double d = b - a;
-    return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
-}
-
-// The p99 needs sorted[lo] and sorted[hi] with lo = floor(0.99 (L - 1)): the (L - lo)-th largest value and its neighbour,
-// about 1 % of the log from the top.  One WAVEFRONT per environment holds the log in registers (SEL_PER_LANE values per
-// lane) and extracts maxima one at a time (lane-local maximum, wavefront maximum by shuffles, the lowest owning lane drops
-// one copy): a dozen rounds for the default episode's ~830 tasks, where the full bitonic sort of metrics_kernel takes 55
-// workgroup barriers.  Same two order statistics, same interpolation: identical results.
-constexpr int SEL_PER_LANE = 32;                 // logs up to 2,048 tasks; larger ones take metrics_kernel
-constexpr int SEL_MAX_ROUNDS = 64;
+// Episode metrics (MRRL.PY:470-504), one WAVEFRONT per environment.  The p99 needs sorted[lo] and sorted[hi] with
+// lo = floor(0.99 (L - 1)), about 1 % of the latency log from the top: the log is held in registers and maxima are extracted
+// one at a time (em_env_math.h: wave_p99; a dozen rounds for the default episode's ~830 tasks); the first version sorted
+// the whole log per workgroup (a bitonic network of 55 barriers: 3.1 ms per episode at 65,536 environments, now 0.34).
+constexpr int SEL_PER_LANE = 32;                 // logs up to 2,048 tasks in registers; larger ones stream from memory
 __global__ __launch_bounds__(256) void metrics_select_kernel(const EnvParams p, const unsigned char* __restrict__ state,
                                                              const EnvConst* __restrict__ cc,
                                                              const double* __restrict__ lat_log, double* __restrict__ out6)
@@ -1365,91 +1347,15 @@ __global__ __launch_bounds__(256) void metrics_select_kernel(const EnvParams p, 
     const double* scal = reinterpret_cast<const double*>(rec + rec_off_scal(n));
     const int32_t* ri = reinterpret_cast<const int32_t*>(rec + rec_off_int(n));
     const int tasks = ri[I_TASKS];
-    const int logged = ri[I_LOGGED];
+    const int logged = lat_log ? ri[I_LOGGED] : 0;
     double p99 = __builtin_nan("");
     if (tasks == 0) p99 = 0.0;
-    else if (logged == tasks) {
-        int lo, hi;
-        double t;
-        p99_indices(logged, lo, hi, t);
-        const int k_lo = logged - 1 - lo, k_hi = logged - 1 - hi;      // ranks from the top (0 = maximum), k_hi <= k_lo
-        // k_lo <= 0.01 L + 1 <= 22 for the L <= 2,048 that the host sends here: the guard cannot trigger (NaN if it did)
-        if (k_lo < SEL_MAX_ROUNDS && logged <= 64 * SEL_PER_LANE) {
-            double v[SEL_PER_LANE];
-#pragma unroll
-            for (int j = 0; j < SEL_PER_LANE; ++j) {
-                const int i = j * 64 + lane;
-                v[j] = i < logged ? lat_log[env * p.lat_cap + i] * 1000 : -__builtin_inf();
-            }
-            double a = 0.0, b = 0.0;
-            for (int r = 0; r <= k_lo; ++r) {
-                double m = v[0];
-#pragma unroll
-                for (int j = 1; j < SEL_PER_LANE; ++j) m = v[j] > m ? v[j] : m;
-                double w = m;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(w, d); w = o > w ? o : w; }
-                if (r == k_hi) b = w;
-                if (r == k_lo) a = w;
-                const unsigned long long own = __ballot(m == w);
-                if (lane == __ffsll(own) - 1) {                        // drop ONE copy of the maximum
-                    bool gone = false;
-#pragma unroll
-                    for (int j = 0; j < SEL_PER_LANE; ++j)
-                        if (!gone && v[j] == w) { v[j] = -__builtin_inf(); gone = true; }
-                }
-            }
-            p99 = p99_lerp(a, b, t);
-        }
+    else if (lat_log && logged == tasks) {
+        p99 = wave_p99_any<SEL_PER_LANE>(lat_log + env * p.lat_cap, logged, lane);
     }
     if (lane == 0) write_metrics(p, cc, scal, ri, p99, out6 + env * 6);
 }
 
-__global__ __launch_bounds__(256) void metrics_kernel(const EnvParams p, const unsigned char* __restrict__ state,
-                                                      const EnvConst* __restrict__ cc,
-                                                      const double* __restrict__ lat_log, double* __restrict__ scratch,
-                                                      double* __restrict__ out6)
-{
-    // one workgroup per environment: the p99 needs a sort of that environment's latencies
-    const int64_t env = blockIdx.x;
-    const int n = p.n;
-    const unsigned char* rec = state + env * p.rec_bytes;
-    const double* scal = reinterpret_cast<const double*>(rec + rec_off_scal(n));
-    const int32_t* ri = reinterpret_cast<const int32_t*>(rec + rec_off_int(n));
-    const int tasks = ri[I_TASKS];
-    const int logged = lat_log ? ri[I_LOGGED] : 0;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* v = reinterpret_cast<double*>(smem);   // next pow2 >= logged doubles
-    double p99 = __builtin_nan("");
-    if (tasks == 0) p99 = 0.0;
-    else if (lat_log && logged == tasks) {
-        int m = 1;
-        while (m < logged) m <<= 1;
-        double* buf = (m * 8 <= 128 * 1024) ? v : scratch + env * p.lat_cap * 2;   // large logs sort in HBM scratch
-        for (int i = threadIdx.x; i < m; i += blockDim.x)
-            buf[i] = i < logged ? lat_log[env * p.lat_cap + i] * 1000 : __builtin_inf();
-        __syncthreads();
-        for (int size = 2; size <= m; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = threadIdx.x; i < (m >> 1); i += blockDim.x) {
-                    const int lo = 2 * i - (i & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const double a = buf[lo], b = buf[hi];
-                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
-                }
-                __syncthreads();
-            }
-        }
-        if (threadIdx.x == 0) {
-            int lo, hi;
-            double t;
-            p99_indices(logged, lo, hi, t);                            // numpy 'linear' method
-            p99 = p99_lerp(buf[lo], buf[hi], t);
-        }
-    }
-    if (threadIdx.x == 0) write_metrics(p, cc, scal, ri, p99, out6 + env * 6);
-}
 
 }  // namespace
 
@@ -1472,7 +1378,6 @@ struct em_handle {
     unsigned char* d_state = nullptr;
     EnvConst* d_const = nullptr;
     double* d_lat_log = nullptr;
-    double* d_sort_scratch = nullptr;
     int32_t* d_err = nullptr;
     bool was_reset = false;
 };
@@ -1682,8 +1587,6 @@ int em_create(const em_config* cfg, int64_t n_envs, int device_id, uint64_t seed
     if (e == hipSuccess) e = hipMemset(h->d_err, 0, sizeof(int32_t));
     if (e == hipSuccess && h->lat_cap > 0) {
         e = hipMalloc(&h->d_lat_log, sizeof(double) * (size_t)n_envs * (size_t)h->lat_cap);
-        if (e == hipSuccess && h->lat_cap * 8 > 64 * 1024)
-            e = hipMalloc(&h->d_sort_scratch, sizeof(double) * 2 * (size_t)n_envs * (size_t)h->lat_cap);
     }
     if (e != hipSuccess) {
         em_destroy(h);
@@ -1700,7 +1603,6 @@ int em_destroy(em_handle* h)
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_const) (void)hipFree(h->d_const);
     if (h->d_lat_log) (void)hipFree(h->d_lat_log);
-    if (h->d_sort_scratch) (void)hipFree(h->d_sort_scratch);
     if (h->d_err) (void)hipFree(h->d_err);
     delete h;
     return EM_OK;
@@ -1792,21 +1694,9 @@ int em_episode_metrics(em_handle* h, double* out6, void* stream)
 {
     if (!h || !out6) return em::fail(EM_ERR_INVALID, "em_episode_metrics: null argument");
     const EnvParams p = make_params(h, h->lanes);
-    hipStream_t s = (hipStream_t)stream;
-    if (h->d_lat_log && h->lat_cap <= 64 * SEL_PER_LANE) {
-        hipLaunchKernelGGL(metrics_select_kernel, dim3((unsigned)((h->n_envs + 3) / 4)), dim3(256), 0, s, p, h->d_state, h->d_const,
-                           h->d_lat_log, out6);
-        return em::hip_check(hipGetLastError(), "metrics_select_kernel launch");
-    }
-    int64_t m = 1;
-    while (m < h->lat_cap) m <<= 1;
-    size_t lds = h->d_lat_log ? (size_t)m * 8 : 16;
-    if (lds > 128 * 1024) lds = 16;
-    if (lds > 64 * 1024)
-        EM_HIP(hipFuncSetAttribute((const void*)metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, s, p, h->d_state,
-                       h->d_const, h->d_lat_log, h->d_sort_scratch, out6);
-    return em::hip_check(hipGetLastError(), "metrics_kernel launch");
+    hipLaunchKernelGGL(metrics_select_kernel, dim3((unsigned)((h->n_envs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, h->d_state,
+                       h->d_const, h->d_lat_log, out6);
+    return em::hip_check(hipGetLastError(), "metrics_select_kernel launch");
 }
 
 int em_set_exploration(em_handle* h, int disable_env_exploration, int64_t global_step_counter)

@@ -846,51 +846,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
 }
 
 // Episode metrics (MRRL.PY:470-504); p99 from the latency log when present.  One workgroup per environment.
-__global__ __launch_bounds__(256) void scaled_metrics_kernel(const ScaledParams p, const unsigned char* __restrict__ state,
-                                                             const EnvConst* __restrict__ cc, const double* __restrict__ lat_log,
-                                                             double* __restrict__ scratch, double* __restrict__ out6)
+// Episode metrics, one wavefront per environment; p99 by selection (em_env_math.h: wave_p99): logs up to 4,096 tasks in
+// registers (the default scaled episode logs about 2,300-2,900: some 30 extraction rounds), larger ones streamed.
+constexpr int SSEL_PER_LANE = 64;
+__global__ __launch_bounds__(256) void scaled_metrics_select_kernel(const ScaledParams p, const unsigned char* __restrict__ state,
+                                                                    const EnvConst* __restrict__ cc,
+                                                                    const double* __restrict__ lat_log, double* __restrict__ out6)
 {
-    const int64_t env = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= p.n_envs) return;
     const int S = p.S;
     const unsigned char* rec = state + env * (int64_t)p.rec_bytes;
     const double* scal = reinterpret_cast<const double*>(rec + srec_off_scal(S));
     const int32_t* ri = reinterpret_cast<const int32_t*>(rec + srec_off_int(S));
     const int tasks = ri[SI_TASKS];
     const int logged = lat_log ? ri[SI_LOGGED] : 0;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* v = reinterpret_cast<double*>(smem);
     double p99 = __builtin_nan("");
     if (tasks == 0) p99 = 0.0;
-    else if (lat_log && logged == tasks) {
-        int m = 1;
-        while (m < logged) m <<= 1;
-        double* buf = (m * 8 <= 128 * 1024) ? v : scratch + env * p.lat_cap * 2;   // large logs sort in HBM scratch
-        for (int i = threadIdx.x; i < m; i += blockDim.x)
-            buf[i] = i < logged ? lat_log[env * p.lat_cap + i] * 1000 : __builtin_inf();
-        __syncthreads();
-        for (int size = 2; size <= m; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = threadIdx.x; i < (m >> 1); i += blockDim.x) {
-                    const int lo = 2 * i - (i & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const double a = buf[lo], b = buf[hi];
-                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
-                }
-                __syncthreads();
-            }
-        }
-        if (threadIdx.x == 0) {
-            const double vi = (double)(logged - 1) * (99.0 / 100.0);   // numpy 'linear' method
-            const double fl = floor(vi);
-            int lo = (int)fl, hi = lo + 1;
-            if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
-            if (hi > logged - 1) hi = logged - 1;
-            const double a = buf[lo], b = buf[hi], t = vi - fl, d = b - a;
-            p99 = (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
-        }
-    }
-    if (threadIdx.x == 0) {
+    else if (lat_log && logged == tasks) p99 = wave_p99_any<SSEL_PER_LANE>(lat_log + env * p.lat_cap, logged, lane);
+    if (lane == 0) {
         double* o = out6 + env * 6;
         const double cnt = (double)(tasks ? tasks : 1);
         o[0] = tasks ? scal[SS_SUMLAT] * 1000 / (double)tasks : 0.0;
@@ -899,7 +874,6 @@ __global__ __launch_bounds__(256) void scaled_metrics_kernel(const ScaledParams 
         o[3] = (double)ri[SI_VIOL] / cnt;
         const double el = scal[SS_ELAPSED];
         o[4] = (double)ri[SI_DONE] / (el > 1e-6 ? el : 1e-6);
-        // Jain index over per-server mean cpu usage; usage sample of a step = cap*dt/(cap+1e-9) (MRRL.PY:379-381)
         const double samples = (double)(ri[SI_STEP] + 1);
         double s1 = 0.0, s2 = 0.0;
         for (int i = 0; i < S; ++i) {
@@ -910,6 +884,7 @@ __global__ __launch_bounds__(256) void scaled_metrics_kernel(const ScaledParams 
         o[5] = (s1 * s1) / ((double)S * s2 + 1e-9);
     }
 }
+
 
 }  // namespace
 
@@ -930,7 +905,6 @@ struct ems_handle {
     unsigned char* d_state = nullptr;
     EnvConst* d_const = nullptr;
     double* d_lat_log = nullptr;
-    double* d_sort_scratch = nullptr;
     int32_t* d_err = nullptr;
     // scalar chain computed ahead by scaled_chain_kernel: rows [chain_first, chain_first + chain_rows) of steps
     double* d_chain_clock = nullptr;   // [n_envs] sim_time after the last computed row
@@ -1045,8 +1019,6 @@ int ems_create(const em_config* cfg, int32_t n_deciders, int64_t n_envs, int dev
     if (e == hipSuccess) e = hipMalloc(&h->d_chain_n, sizeof(int32_t) * (size_t)n_envs * CHAIN_ROWS);
     if (e == hipSuccess && h->lat_cap > 0) {
         e = hipMalloc(&h->d_lat_log, sizeof(double) * (size_t)n_envs * (size_t)h->lat_cap);
-        if (e == hipSuccess && h->lat_cap * 8 > 64 * 1024)
-            e = hipMalloc(&h->d_sort_scratch, sizeof(double) * 2 * (size_t)n_envs * (size_t)h->lat_cap);
     }
     if (e != hipSuccess) {
         ems_destroy(h);
@@ -1063,7 +1035,6 @@ int ems_destroy(ems_handle* h)
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_const) (void)hipFree(h->d_const);
     if (h->d_lat_log) (void)hipFree(h->d_lat_log);
-    if (h->d_sort_scratch) (void)hipFree(h->d_sort_scratch);
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_chain_clock) (void)hipFree(h->d_chain_clock);
     if (h->d_chain_win) (void)hipFree(h->d_chain_win);
@@ -1154,15 +1125,9 @@ int ems_episode_metrics(ems_handle* h, double* out6, void* stream)
 {
     if (!h || !out6) return em::fail(EM_ERR_INVALID, "ems_episode_metrics: null argument");
     const ScaledParams p = make_sparams(h);
-    int64_t m = 1;
-    while (m < h->lat_cap) m <<= 1;
-    size_t lds = h->d_lat_log ? (size_t)m * 8 : 16;
-    if (lds > 128 * 1024) lds = 16;
-    if (lds > 64 * 1024)
-        EM_HIP(hipFuncSetAttribute((const void*)scaled_metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(scaled_metrics_kernel, dim3((unsigned)h->n_envs), dim3(256), lds, (hipStream_t)stream, p, h->d_state,
-                       h->d_const, h->d_lat_log, h->d_sort_scratch, out6);
-    return em::hip_check(hipGetLastError(), "scaled_metrics_kernel launch");
+    hipLaunchKernelGGL(scaled_metrics_select_kernel, dim3((unsigned)((h->n_envs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                       h->d_state, h->d_const, h->d_lat_log, out6);
+    return em::hip_check(hipGetLastError(), "scaled_metrics_select_kernel launch");
 }
 
 int ems_set_exploration(ems_handle* h, int disable_env_exploration, int64_t global_step_counter)

@@ -141,6 +141,96 @@ __device__ inline double np_sum_small(const double* a, int n)
     return 0.0 + res;
 }
 
+// np.percentile(x, 99) ('linear' method) from the two order statistics it interpolates: a = sorted[lo], b = sorted[hi]
+__device__ inline void p99_indices(int logged, int& lo, int& hi, double& t)
+{
+    const double vi = (double)(logged - 1) * (99.0 / 100.0);
+    const double fl = floor(vi);
+    lo = (int)fl; hi = lo + 1;
+    if (vi >= (double)(logged - 1)) { lo = logged - 1; hi = logged - 1; }
+    if (hi > logged - 1) hi = logged - 1;
+    t = vi - fl;
+}
+__device__ inline double p99_lerp(double a, double b, double t)
+{
+    const double d = b - a;
+    return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;
+}
+
+// p99 (in ms) of one environment's latency log (seconds) by SELECTION: the log sits in one wavefront's registers (PL values
+// per lane, logged <= 64 PL) and maxima are extracted one at a time (lane-local maximum, wavefront maximum by shuffles, the
+// lowest owning lane drops one copy) down to the two order statistics np.percentile interpolates, about 1 % of the log
+// from the top.  All 64 lanes call it; same values as sorting.  NaN if the log does not fit (logged > 64 PL).
+template <int PL>
+__device__ inline double wave_p99(const double* __restrict__ log, int logged, int lane)
+{
+    int lo, hi;
+    double t;
+    p99_indices(logged, lo, hi, t);
+    const int k_lo = logged - 1 - lo, k_hi = logged - 1 - hi;      // ranks from the top (0 = maximum), k_hi <= k_lo
+    if (logged > 64 * PL) return __builtin_nan("");
+    double v[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        const int i = j * 64 + lane;
+        v[j] = i < logged ? log[i] * 1000 : -__builtin_inf();
+    }
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r <= k_lo; ++r) {
+        double m = v[0];
+#pragma unroll
+        for (int j = 1; j < PL; ++j) m = v[j] > m ? v[j] : m;
+        double w = m;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(w, d); w = o > w ? o : w; }
+        if (r == k_hi) b = w;
+        if (r == k_lo) a = w;
+        const unsigned long long own = __ballot(m == w);
+        if (lane == __ffsll(own) - 1) {                            // drop ONE copy of the maximum
+            bool gone = false;
+#pragma unroll
+            for (int j = 0; j < PL; ++j)
+                if (!gone && v[j] == w) { v[j] = -__builtin_inf(); gone = true; }
+        }
+    }
+    return p99_lerp(a, b, t);
+}
+
+// The same two order statistics for a log that does not fit the registers: distinct values are visited from the top, each
+// visit one pass over the log in memory (maximum below the previous value, and how many copies of it there are).  One pass
+// per distinct value among the top 1 %: slow, and only taken by an environment that logged more than 64 PL tasks.
+__device__ inline double wave_p99_stream(const double* __restrict__ log, int logged, int lane)
+{
+    int lo, hi;
+    double t;
+    p99_indices(logged, lo, hi, t);
+    const int k_lo = logged - 1 - lo, k_hi = logged - 1 - hi;
+    double a = 0.0, b = 0.0, thr = __builtin_inf();
+    int pos = 0;
+    while (pos <= k_lo) {
+        double m = -__builtin_inf();
+        for (int i = lane; i < logged; i += 64) { const double x = log[i] * 1000; if (x < thr && x > m) m = x; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(m, d); m = o > m ? o : m; }
+        int c = 0;
+        for (int i = lane; i < logged; i += 64) c += (log[i] * 1000 == m) ? 1 : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        if (c <= 0) break;                                         // cannot happen for finite latencies; no endless loop on NaN
+        if (k_hi >= pos && k_hi < pos + c) b = m;
+        if (k_lo >= pos && k_lo < pos + c) a = m;
+        pos += c;
+        thr = m;
+    }
+    return p99_lerp(a, b, t);
+}
+
+template <int PL>
+__device__ inline double wave_p99_any(const double* __restrict__ log, int logged, int lane)
+{
+    return logged <= 64 * PL ? wave_p99<PL>(log, logged, lane) : wave_p99_stream(log, logged, lane);   // wave-uniform
+}
+
 inline EnvConst make_const(const em_config& c)
 {
     EnvConst k;

@@ -423,6 +423,33 @@ def test_exact_p99_at_4096_envs_with_the_default_latency_log():
     assert tasks.max() < env.latency_log_capacity and tasks.min() > 500
 
 
+def test_exact_p99_for_logs_larger_than_the_register_file():
+    """More than 2,048 logged tasks per environment (thirty times the default arrival rate: about five acting agents per step): the p99 selection leaves its
+    register path and streams the log from memory; still the C restatement's value bit for bit, ties included (a fixed
+    action repeats many latencies)."""
+    from marl_amd.env import BatchedEdgeSimGym
+    cfg = eo.default_config()
+    cfg.update(disable_env_exploration=True, task_arrival_rate=300, task_arrival_rate_range=(200, 400), episode_length=700)
+    B, n, T = 96, 10, 700
+    env = BatchedEdgeSimGym(cfg, n_envs=B, device="cuda:0", seed=21)
+    ref = c_oracle.COracleEnv(cfg, B, seed=21, env_offset=0)
+    ref.set_explore(True, 0)
+    ref.next_episode()
+    ref.reset()
+    env.reset()
+    rs = np.random.RandomState(6)
+    for t in range(T):
+        pl = rs.randint(0, n, size=(B, n)).astype(np.int32)
+        rsrc = np.full((B, n), 0.5, np.float32)
+        ref.step(pl, rsrc)
+        env.step(torch.as_tensor(pl).cuda(), torch.as_tensor(rsrc).cuda())
+    m, rm = env.episode_metrics().cpu().numpy(), ref.metrics()
+    tasks = env.get_state()["counts"][:, 0]
+    assert tasks.min() > 2048 and tasks.max() < env.latency_log_capacity, (tasks.min(), tasks.max())
+    assert not np.isnan(m).any()
+    assert np.array_equal(m[:, [1, 3, 4]], rm[:, [1, 3, 4]])
+
+
 def test_overflowing_latency_log_reports_nan_never_zero():
     """An environment whose log is too small reports NaN for p99 (and only p99); the trainer-level summary leaves such
     environments out of the mean and counts them instead of reporting 0.0."""
