@@ -202,14 +202,17 @@ def test_states_by_reference_equal_compact_copies():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("n_envs,explore", [(700, True), (700, False), (5, True), (4099, True)])
-def test_one_launch_index_and_policy_equals_the_two_launches(n_envs, explore):
+@pytest.mark.parametrize("n_envs,explore,n_nodes", [(700, True, 10), (700, False, 10), (5, True, 10), (4099, True, 10),
+                                                    (300, True, 6), (300, True, 8), (300, True, 2)])
+def test_one_launch_index_and_policy_equals_the_two_launches(n_envs, explore, n_nodes):
     """em_rollout_policy_step (entries numbered, copied and the actor evaluated on them in one kernel) against
     em_rollout_index_totals followed by em_policy_step: every stored value, the actions handed to the environment and the
     update that follows are identical bit for bit (partial chunks, a batch smaller than one tile, evaluation mode)."""
     from marl_amd.config import ENV_CONFIG
     from marl_amd.trainer import MAPPOTrainer
     cfg = dict(ENV_CONFIG, episode_length=40)
+    if n_nodes != 10:       # the kernel's generic instantiation (node count read from the arguments)
+        cfg.update(n_nodes=n_nodes, node_cpu_capacity=list(np.linspace(1.0e9, 3.0e9, n_nodes)))
     outs = []
     for fused in (True, False):
         tr = MAPPOTrainer(cfg, seed=9, device="cuda:0", n_envs=n_envs, verbose=False)
