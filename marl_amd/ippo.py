@@ -64,6 +64,8 @@ class ScaledRolloutStorage:
         self.t["counters"].zero_()
         self.t["k_tb"].zero_()
         self.steps_recorded = 0
+        self.values_through = 0           # recorded steps whose entries have a value (deferred critic, IPPO.compute_values)
+        self.group_cache = None           # ((entries, steps), offsets, permutation) of IPPO._grouping
 
     def total_raw(self):
         """(entries recorded so far, error flag), without raising; synchronises."""
@@ -121,6 +123,7 @@ class IPPO:
         # side stream beside the policy forward and the environment step (overlap_value); join_value() orders the main
         # stream behind it again (called before the next step's index overwrites group_off/perm, and by update())
         self.overlap_value = False
+        self.defer_values = True          # values of a recorded rollout: one launch over all entries (compute_values)
         self._side = self._ev_idx = self._ev_val = None
         self._value_pending = False
 
@@ -152,14 +155,44 @@ class IPPO:
                                                  env.pend_decider.data_ptr(), env.pend_obs.data_ptr(), _stream(self.device)),
                        "ems_rollout_index")
         value = lambda: gmlp.value(self.critic, tt["ent_obs"], tt["ent_value"], tt["group_off"], tt["perm"], self.fwd_split)  # noqa: E731
-        if self.overlap_value:
+        defer = self.defer_values and ro.horizon > 1
+        if defer:
+            value = lambda: None  # noqa: E731  (update() evaluates every recorded entry in one launch before GAE)
+        elif self.overlap_value:
             self._value_async(value)
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
                     tt["ent_action"], tt["ent_logp"], tt["group_off"], tt["perm"], self.fwd_split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
-        if not self.overlap_value:
+        if defer or not self.overlap_value:
             value()
         ro.steps_recorded = t + 1
+
+    def _grouping(self, E):
+        """Entries [0, E) grouped by learner: (offsets, permutation), stable (fixed summation order per learner); cached
+        for the (E, steps recorded) it was built for."""
+        ro = self.buffer
+        key = (E, ro.steps_recorded)
+        if getattr(ro, "group_cache", None) is None or ro.group_cache[0] != key:
+            dev = self.device
+            if self.G > 1:
+                off, perm = gmlp.group_index(self.buffer.t["ent_agent"][:E], self.G)
+            else:
+                off, perm = torch.tensor([0, E], dtype=torch.int64, device=dev), None
+            ro.group_cache = (key, off, perm)
+        return ro.group_cache[1], ro.group_cache[2]
+
+    def compute_values(self):
+        """Deferred mode: the critics' forward over every recorded entry that has no value yet, in one launch (the rollout
+        needs no value before GAE, and the per-step value launch could never share a CU with the policy launch: their
+        registers do not fit together).  A no-op otherwise."""
+        ro = self.buffer
+        if not (self.defer_values and ro.horizon > 1) or getattr(ro, "values_through", 0) == ro.steps_recorded:
+            return
+        E = ro.total()
+        if E > 0:
+            off, perm = self._grouping(E)
+            gmlp.value(self.critic, ro.t["ent_obs"][:E], ro.t["ent_value"], off, perm, self.split)
+        ro.values_through = ro.steps_recorded
 
     # -- update ----------------------------------------------------------------------------------------------------------
     def update(self):
@@ -170,18 +203,16 @@ class IPPO:
             return {}
         tt, L, dev = ro.t, self._L, self.device
         x = tt["ent_obs"][:E]
+        off = perm = None
         if E > 0:
+            off, perm = self._grouping(E)
+            self.compute_values()
             with torch.cuda.device(dev):
                 _lib.check(L.em_gae_agents(ro.n_envs, ro.steps_recorded, self.D, tt["reward_tb"].data_ptr(), tt["done_tb"].data_ptr(),
                                            tt["k_tb"].data_ptr(), tt["first_tb"].data_ptr(), tt["ent_agent"].data_ptr(),
                                            tt["ent_value"].data_ptr(), float(self.gamma), float(self.gae_lambda),
                                            self._chain.data_ptr(), tt["ent_adv"].data_ptr(), tt["ent_ret"].data_ptr(), _stream(dev)),
                            "em_gae_agents")
-            if self.G > 1:
-                off, perm = gmlp.group_index(tt["ent_agent"][:E], self.G)      # stable: fixed summation order per learner
-            else:
-                off = torch.tensor([0, E], dtype=torch.int64, device=dev)
-                perm = None
             gmlp.group_moments(tt["ent_adv"], off, perm, self.G, self.moments)
         else:                                # empty shard: zero moments, zero gradients, every collective still joined
             self.moments.zero_()
@@ -337,6 +368,8 @@ class IPPOTrainer:
             a.buffer = self._train_storage
         if record_buffer:
             total_reward = ro.t["reward_tb"][:T].sum(dim=0)
+            if hasattr(a, "compute_values") and self.algorithm != "mappo":
+                a.compute_values()
         metrics = env.episode_metrics()
         mean, p99_missing = summarise_episode_metrics(metrics, env.n_pending > 0)      # mappo_trainer.py:222-231
         idx = {k: i for i, k in enumerate(METRIC_KEYS)}
