@@ -87,7 +87,7 @@ struct Lds {
                          B3 = B2 + HID, LS = B3 + 16 * OT, END = LS + 16 * OT;
 };
 
-template <int KU, int OT>
+template <int KU, int OT, int NT = 256>
 __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float* log_std, int g)
 {
     using L = Lds<KU, OT>;
@@ -98,19 +98,19 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
     const float* w3 = net.w3 + go;
     // fixed trip counts, read in batches of 8 before anything is written: as plain loops every iteration waited for its own
     // load (56 L2 round trips in a row, 28 k cycles by in-kernel stamps - half of a rollout launch of the policy kernel)
-    constexpr int N1 = HID * L::K1P / 256, N2 = HID * HID / 256, N3 = 16 * OT * HID / 256, BATCH = 8;
-    static_assert(HID * L::K1P % 256 == 0 && 16 * OT * HID % 256 == 0, "whole passes of the workgroup");
+    constexpr int N1 = HID * L::K1P / NT, N2 = HID * HID / NT, N3 = 16 * OT * HID / NT, BATCH = 8;
+    static_assert(HID * L::K1P % NT == 0 && 16 * OT * HID % NT == 0 && HID * HID % NT == 0, "whole passes of the workgroup");
 #pragma unroll
     for (int j0 = 0; j0 < N1; j0 += BATCH) {
         float v[BATCH];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int i = (j0 + j) * 256 + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
+            const int i = (j0 + j) * NT + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
             v[j] = (j0 + j < N1 && k < K1) ? w1[r * K1 + k] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int i = (j0 + j) * 256 + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
+            const int i = (j0 + j) * NT + threadIdx.x, r = i / L::K1P, k = i - r * L::K1P;
             if (j0 + j < N1) lds[L::W1 + r * L::S1 + k] = v[j];
         }
     }
@@ -118,10 +118,10 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
     for (int j0 = 0; j0 < N2; j0 += BATCH) {
         float v[BATCH];
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) v[j] = (j0 + j < N2) ? w2[(j0 + j) * 256 + threadIdx.x] : 0.0f;
+        for (int j = 0; j < BATCH; ++j) v[j] = (j0 + j < N2) ? w2[(j0 + j) * NT + threadIdx.x] : 0.0f;
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int i = (j0 + j) * 256 + threadIdx.x;
+            const int i = (j0 + j) * NT + threadIdx.x;
             if (j0 + j < N2) lds[L::W2 + (i >> 6) * S2 + (i & 63)] = v[j];
         }
     }
@@ -130,12 +130,12 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
         float v[BATCH];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int i = (j0 + j) * 256 + threadIdx.x;
+            const int i = (j0 + j) * NT + threadIdx.x;
             v[j] = (j0 + j < N3 && (i >> 6) < O) ? w3[i] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int i = (j0 + j) * 256 + threadIdx.x;
+            const int i = (j0 + j) * NT + threadIdx.x;
             if (j0 + j < N3) lds[L::W3 + (i >> 6) * S2 + (i & 63)] = v[j];
         }
     }
@@ -153,11 +153,20 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
 struct NoHook { __device__ void operator()() const {} };
 // after_l1 runs once the first layer's products are issued (the x fragment is dead from there: a caller can start loads
 // that the epilogue needs into the registers it frees)
-template <int KU, int OT, class Hook = NoHook>
-__device__ inline void forward_tile(const float* lds, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
+// PER_TILE: the weight fragments are re-read from LDS for every tile (the base address passes through an empty asm, so
+// the compiler cannot hoist the 400-odd loop-invariant reads out of the caller's tile loop into registers, or, with two
+// wavefronts per SIMD and 256 registers, into scratch)
+template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false>
+__device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
                                     f32x4 (&y)[OT], Hook after_l1 = Hook())
 {
     using L = Lds<KU, OT>;
+    const float* lds = lds_in;
+    if constexpr (PER_TILE) {
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        lds = lds_in + zero;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -228,8 +237,10 @@ __device__ inline void load_x_frag(const GArgs& a, int64_t grow, bool valid, int
     }
 }
 
-template <int KU, int OT, int MODE>
-__global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
+// NW wavefronts per workgroup: a group's tiles (about nine per learner and step in the IPPO rollout) are dealt to more
+// wavefronts, two per SIMD, so that one's epilogue arithmetic runs under the other's MFMAs
+template <int KU, int OT, int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     using L = Lds<KU, OT>;
@@ -239,8 +250,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
     const int g = blockIdx.x / a.split, part = blockIdx.x - g * a.split;
     const int64_t r0 = a.group_off ? a.group_off[g] : 0, r1 = a.group_off ? a.group_off[g + 1] : a.n_rows;
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
-    if ((int64_t)part * 4 >= n_tiles) return;          // uniform over the workgroup: safe before the barrier
-    stage_weights<KU, OT>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g);
+    if ((int64_t)part * NW >= n_tiles) return;         // uniform over the workgroup: safe before the barrier
+    stage_weights<KU, OT, 64 * NW>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g);
     __syncthreads();
     // sigma = exp(log_std) of every output, once per workgroup (the same expression, so the same bits as evaluating it per
     // element and tile in the epilogue, where it cost 4 x OT exp() per row)
@@ -250,14 +261,14 @@ __global__ __launch_bounds__(256, 1) void gmlp_fwd_kernel(const GArgs a)
         __syncthreads();
     }
 
-    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
+    for (int64_t tile = (int64_t)part * NW + wave; tile < n_tiles; tile += (int64_t)a.split * NW) {
         const int64_t row = tile * 16 + c;
         const bool valid = row < n_rows;
         const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
         float xb[KU * 4];
         load_x_frag<KU>(a, grow, valid, q, xb);
         f32x4 h1[4], h2[4], y[OT];
-        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y);
+        forward_tile<KU, OT, NoHook, (NW > 4)>(lds, xb, q, c, h1, h2, y);
 
         if constexpr (MODE == MODE_PLAIN) {
             if (valid) {
@@ -846,18 +857,22 @@ int set_lds(K kernel, size_t lds)
     return EM_OK;
 }
 
+#ifndef EM_GFWD_WAVES
+#define EM_GFWD_WAVES 8
+#endif
 // in_dim <= 80 -> KU = 5 (one instantiation keeps the library small; narrower inputs are zero padded in LDS)
 template <int MODE>
 int launch_gfwd(const GArgs& ga, hipStream_t s)
 {
     const int ot = (ga.net.out_dim + 15) / 16;
-    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(256);
+    constexpr int NW = EM_GFWD_WAVES;
+    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(64 * NW);
 #define EM_GF(OT_)                                                                                    \
     case OT_: {                                                                                       \
         const size_t lds = lds_bytes(5, OT_, false);                                                  \
-        const int rc = set_lds(gmlp_fwd_kernel<5, OT_, MODE>, lds);                                   \
+        const int rc = set_lds(gmlp_fwd_kernel<5, OT_, MODE, NW>, lds);                               \
         if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((gmlp_fwd_kernel<5, OT_, MODE>), grid, block, lds, s, ga);                 \
+        hipLaunchKernelGGL((gmlp_fwd_kernel<5, OT_, MODE, NW>), grid, block, lds, s, ga);             \
     } break
     switch (ot) {
         EM_GF(1); EM_GF(2); EM_GF(3); EM_GF(4); EM_GF(5);
