@@ -7,6 +7,22 @@
 
 namespace {
 
+// Philox4x32-10 (the environment kernels' generator, em_env_math.h, restated for the float32 translation units).  One
+// 32x32->64 product per half round (v_mad_u64_u32): as separate v_mul_hi_u32 / v_mul_lo_u32, both quarter-rate, the 40
+// multiplies of a block were most of the policy epilogue's issue cycles (five blocks per lane and tile at 65 outputs).
+__device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0;
+        const uint32_t hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
 // sin and cos of 2*pi*u for u in [0, 1): the argument is reduced EXACTLY (u - j/4 is representable for a 24-bit u), then one
 // polynomial pair on [-pi/4, pi/4].  More accurate than sincosf(2*pi*u), whose float argument is already rounded, and
 // free of its large-argument path.

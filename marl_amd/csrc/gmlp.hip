@@ -30,18 +30,6 @@ constexpr int TS = 17;      // row stride of the transpose scratch (floats)
 constexpr int S2 = 66;      // LDS row stride of 64-wide weight matrices (2*odd: conflict-free fragment reads)
 constexpr float HALF_LOG_2PI = 0.91893853320467274f;
 
-__device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-
 enum { P_NOISE = 8 };
 enum { MODE_PLAIN = 0, MODE_POLICY = 1, MODE_VALUE = 2 };
 
@@ -88,14 +76,25 @@ struct Lds {
 };
 
 template <int KU, int OT, int NT = 256>
-__device__ inline void stage_weights(float* lds, const em_gmlp& net, const float* log_std, int g)
+__device__ inline void stage_weights(float* lds, const em_gmlp& net, const float* log_std, int g, float* sigma = nullptr,
+                                     int K1c = 0, int Oc = 0)
 {
     using L = Lds<KU, OT>;
-    const int K1 = net.in_dim, O = net.out_dim;
+    const int K1 = K1c ? K1c : net.in_dim, O = Oc ? Oc : net.out_dim;
     const int64_t go = (int64_t)g * net.group_stride;
     const float* w1 = net.w1 + go;
     const float* w2 = net.w2 + go;
     const float* w3 = net.w3 + go;
+    // the small vectors first: loaded after the matrices they were one more L2 round trip in front of the barrier
+    float sb1 = 0.0f, sb2 = 0.0f, sb3 = 0.0f, sls = 0.0f;
+    if (threadIdx.x < HID) {
+        sb1 = net.b1[go + threadIdx.x];
+        sb2 = net.b2[go + threadIdx.x];
+    }
+    if (threadIdx.x < 16 * OT && (int)threadIdx.x < O) {
+        sb3 = net.b3[go + threadIdx.x];
+        if (log_std) sls = log_std[go + threadIdx.x];
+    }
     // fixed trip counts, read in batches of 8 before anything is written: as plain loops every iteration waited for its own
     // load (56 L2 round trips in a row, 28 k cycles by in-kernel stamps - half of a rollout launch of the policy kernel)
     constexpr int N1 = HID * L::K1P / NT, N2 = HID * HID / NT, N3 = 16 * OT * HID / NT, BATCH = 8;
@@ -140,12 +139,15 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
         }
     }
     if (threadIdx.x < HID) {
-        lds[L::B1 + threadIdx.x] = net.b1[go + threadIdx.x];
-        lds[L::B2 + threadIdx.x] = net.b2[go + threadIdx.x];
+        lds[L::B1 + threadIdx.x] = sb1;
+        lds[L::B2 + threadIdx.x] = sb2;
     }
     if (threadIdx.x < 16 * OT) {
-        lds[L::B3 + threadIdx.x] = (int)threadIdx.x < O ? net.b3[go + threadIdx.x] : 0.0f;
-        lds[L::LS + threadIdx.x] = (log_std && (int)threadIdx.x < O) ? log_std[go + threadIdx.x] : 0.0f;
+        lds[L::B3 + threadIdx.x] = sb3;
+        lds[L::LS + threadIdx.x] = sls;
+        // sigma = exp(log_std) of every output, once per workgroup (the same expression, so the same bits as evaluating it
+        // per element and tile in the epilogue, where it cost 4 x OT exp() per row)
+        if (sigma) sigma[threadIdx.x] = expf(sls);
     }
 }
 
@@ -214,10 +216,10 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
     // y[ot][r] = out[row c][o = 16 ot + 4q + r]
 }
 
-template <int KU>
+template <int KU, int KC = 0>
 __device__ inline void load_x_frag(const GArgs& a, int64_t grow, bool valid, int q, float (&xb)[KU * 4])
 {
-    const int K1 = a.net.in_dim;
+    const int K1 = KC ? KC : a.net.in_dim;
     const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     const float* xr = a.x + (valid ? grow : 0) * a.ldx;
 #pragma unroll
@@ -239,36 +241,45 @@ __device__ inline void load_x_frag(const GArgs& a, int64_t grow, bool valid, int
 
 // NW wavefronts per workgroup (16 by default: 95 vs 101 ms per IPPO rollout with 8, 112 with 4): a group's tiles (about nine per learner and step in the IPPO rollout) are dealt to more
 // wavefronts, two per SIMD, so that one's epilogue arithmetic runs under the other's MFMAs
-template <int KU, int OT, int MODE, int NW = 4>
+#ifdef EM_STAMP_GFWD   // cycle stamps of every wavefront of one workgroup (tools/stamp_gfwd.py)
+__device__ unsigned long long gfwd_stamps[16 * 8];
+#define GSTAMP(i) do { if (MODE == MODE_POLICY && blockIdx.x == 7 && (threadIdx.x & 63) == 0) gfwd_stamps[(threadIdx.x >> 6) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+// KC, OC: in_dim and out_dim as compile-time constants (0 = read from the arguments; policy: n_place = OC - 1).  With
+// run-time widths every "is this column real" test of the epilogue (3 per element, 20 elements per lane) is a
+// loop-invariant lane mask: the compiler hoisted 200 SGPRs of them out of the tile loop, spilled them into VGPR lanes and
+// paid a v_readlane plus hazard nops for each one in every tile.
+template <int KU, int OT, int MODE, int NW = 4, int KC = 0, int OC = 0>
 __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
 {
+    GSTAMP(0);
     extern __shared__ __align__(16) float lds[];
     using L = Lds<KU, OT>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    const int O = a.net.out_dim;
+    const int O = OC ? OC : a.net.out_dim;
     const int g = blockIdx.x / a.split, part = blockIdx.x - g * a.split;
     const int64_t r0 = a.group_off ? a.group_off[g] : 0, r1 = a.group_off ? a.group_off[g + 1] : a.n_rows;
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
     if ((int64_t)part * NW >= n_tiles) return;         // uniform over the workgroup: safe before the barrier
-    stage_weights<KU, OT, 64 * NW>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g);
-    __syncthreads();
-    // sigma = exp(log_std) of every output, once per workgroup (the same expression, so the same bits as evaluating it per
-    // element and tile in the epilogue, where it cost 4 x OT exp() per row)
     float* sd_t = lds + L::END;
-    if constexpr (MODE == MODE_POLICY) {
-        if (threadIdx.x < 16 * OT) sd_t[threadIdx.x] = expf(lds[L::LS + threadIdx.x]);
-        __syncthreads();
-    }
+    stage_weights<KU, OT, 64 * NW>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g, MODE == MODE_POLICY ? sd_t : nullptr, KC, OC);
+    GSTAMP(1);
+    __syncthreads();
 
     for (int64_t tile = (int64_t)part * NW + wave; tile < n_tiles; tile += (int64_t)a.split * NW) {
+        GSTAMP(2);
         const int64_t row = tile * 16 + c;
         const bool valid = row < n_rows;
         const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
         float xb[KU * 4];
-        load_x_frag<KU>(a, grow, valid, q, xb);
+        load_x_frag<KU, KC>(a, grow, valid, q, xb);
         f32x4 h1[4], h2[4], y[OT];
+        GSTAMP(3);
         forward_tile<KU, OT, NoHook, (NW > 4)>(lds, xb, q, c, h1, h2, y);
+        GSTAMP(4);
 
         if constexpr (MODE == MODE_PLAIN) {
             if (valid) {
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
         } else {
             // ---- policy epilogue: rsample + log-prob (mappo_algorithm.py:62-71,209-213), action formatting
             //      (mappo_trainer.py:125-158) --------------------------------------------------------------
-            const int n = a.n_place;
+            const int n = OC ? OC - 1 : a.n_place;
             const int env = valid ? a.ent_env[grow] : 0;
             const int agent = valid ? a.ent_agent[grow] : 0;
             float lp = 0.0f, best = -__builtin_inff(), res_raw = 0.0f;
@@ -337,9 +348,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
                 a.placement[dst] = place;
                 a.resource[dst] = em_resource_share(res_raw);             // mappo_trainer.py:148-152
             }
+            GSTAMP(5);
         }
     }
+    GSTAMP(6);
 }
+#ifdef EM_STAMP_GFWD
+extern "C" int em_debug_gfwd_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfwd_stamps), sizeof(gfwd_stamps)); }
+#endif
 
 // fused forward-recompute + loss + backward for the rows of one group (mlp3_bwd_kernel generalised)
 // STAGE (rows of K1 % 4 == 0 floats, 16-byte aligned): a tile's 16 input rows are copied ONCE, global -> LDS with no register
@@ -874,6 +890,16 @@ int launch_gfwd(const GArgs& ga, hipStream_t s)
         if (rc) return rc;                                                                            \
         hipLaunchKernelGGL((gmlp_fwd_kernel<5, OT_, MODE, NW>), grid, block, lds, s, ga);             \
     } break
+    if constexpr (MODE == MODE_POLICY) {
+        // the scaled topology's shape (64 servers: 68 inputs, 64 placement logits + the resource share)
+        if (ga.net.in_dim == 68 && ga.net.out_dim == 65 && ga.n_place == 64) {
+            const size_t lds = lds_bytes(5, 5, false);
+            const int rc = set_lds(gmlp_fwd_kernel<5, 5, MODE, NW, 68, 65>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((gmlp_fwd_kernel<5, 5, MODE, NW, 68, 65>), grid, block, lds, s, ga);
+            return em::hip_check(hipGetLastError(), "gmlp_fwd_kernel launch");
+        }
+    }
     switch (ot) {
         EM_GF(1); EM_GF(2); EM_GF(3); EM_GF(4); EM_GF(5);
         default: return em::fail(EM_ERR_INVALID, "gmlp: unsupported out_dim");
