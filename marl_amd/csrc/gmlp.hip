@@ -67,19 +67,23 @@ struct GArgs {
 };
 
 // LDS carve-up shared by forward and backward: W1 [64][S1] | W2 [64][S2] | W3 [16*OT][S2] | b1[64] b2[64] b3[16*OT] ls[16*OT]
-template <int KU, int OT>
+template <int KU, int OT, bool V4 = false>
 struct Lds {
     static constexpr int K1P = KU * 16;
-    static constexpr int S1 = (K1P + 2) | 2;
+    // V4 (forward-only kernels): row strides of 4 * odd floats, so that a lane's four consecutive fragment values are one
+    // aligned ds_read_b128 with a 16-bit immediate offset (no address arithmetic; 16 lanes x 16 B hit 16 different bank
+    // quads) instead of two ds_read2_b32 whose 8-bit offsets needed a v_add each
+    static constexpr int S1 = V4 ? K1P + 4 : (K1P + 2) | 2;
+    static constexpr int S2 = V4 ? HID + 4 : ::S2;
     static constexpr int W1 = 0, W2 = W1 + HID * S1, W3 = W2 + HID * S2, B1 = W3 + 16 * OT * S2, B2 = B1 + HID,
                          B3 = B2 + HID, LS = B3 + 16 * OT, END = LS + 16 * OT;
 };
 
-template <int KU, int OT, int NT = 256>
+template <int KU, int OT, int NT = 256, bool V4 = false>
 __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float* log_std, int g, float* sigma = nullptr,
                                      int K1c = 0, int Oc = 0)
 {
-    using L = Lds<KU, OT>;
+    using L = Lds<KU, OT, V4>;
     const int K1 = K1c ? K1c : net.in_dim, O = Oc ? Oc : net.out_dim;
     const int64_t go = (int64_t)g * net.group_stride;
     const float* w1 = net.w1 + go;
@@ -121,7 +125,7 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
             const int i = (j0 + j) * NT + threadIdx.x;
-            if (j0 + j < N2) lds[L::W2 + (i >> 6) * S2 + (i & 63)] = v[j];
+            if (j0 + j < N2) lds[L::W2 + (i >> 6) * L::S2 + (i & 63)] = v[j];
         }
     }
 #pragma unroll
@@ -135,7 +139,7 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
             const int i = (j0 + j) * NT + threadIdx.x;
-            if (j0 + j < N3) lds[L::W3 + (i >> 6) * S2 + (i & 63)] = v[j];
+            if (j0 + j < N3) lds[L::W3 + (i >> 6) * L::S2 + (i & 63)] = v[j];
         }
     }
     if (threadIdx.x < HID) {
@@ -162,23 +166,36 @@ template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false>
 __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
                                     f32x4 (&y)[OT], Hook after_l1 = Hook())
 {
-    using L = Lds<KU, OT>;
+    using L = Lds<KU, OT, PER_TILE>;      // the per-tile readers use the ds_read_b128 layout
     const float* lds = lds_in;
     if constexpr (PER_TILE) {
         int zero = 0;
         asm volatile("" : "+v"(zero));
         lds = lds_in + zero;
     }
+    auto frag = [&](int base, int u, float (&w)[4]) {   // values k = 16u + 4q + 0..3 of the row at base
+        if constexpr (PER_TILE) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + base + 16 * u + 4 * q);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = lds[base + 16 * u + 4 * q + r];
+        }
+    };
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h1[t][r] = lds[L::B1 + 16 * t + 4 * q + r];
 #pragma unroll
-    for (int s = 0; s < KU * 4; ++s) {
-        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+    for (int u = 0; u < KU; ++u)
+    {   // reduction index outside, accumulator inside: consecutive MFMAs never wait for each other
+        float w[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W1 + (16 * t + c) * L::S1 + k], xb[s], h1[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) frag(L::W1 + (16 * t + c) * L::S1, u, w[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], xb[4 * u + r], h1[t], 0, 0, 0);
     }
     after_l1();
 #pragma unroll
@@ -189,11 +206,15 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
             h2[t][r] = lds[L::B2 + 16 * t + 4 * q + r];
         }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+    for (int u = 0; u < 4; ++u)
+    {
+        float w[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W2 + (16 * t + c) * S2 + k], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) frag(L::W2 + (16 * t + c) * L::S2, u, w[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], h1[u][r], h2[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -203,15 +224,17 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[ot][r] = lds[L::B3 + 16 * ot + 4 * q + r];
-    // reduction index outside, output tile inside: the OT accumulators are independent, so consecutive MFMAs do not wait
-    // for each other (tile by tile, each product waited for the previous one on the same accumulator); the order of the
-    // partial sums of an accumulator is unchanged
+    // the partial sums of an accumulator are taken in the order k = 0, 1, 2, ... in every variant
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+    for (int u = 0; u < 4; ++u)
+    {
+        float w[OT][4];
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
-            y[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + c) * S2 + k], h2[s >> 2][s & 3], y[ot], 0, 0, 0);
+        for (int ot = 0; ot < OT; ++ot) frag(L::W3 + (16 * ot + c) * L::S2, u, w[ot]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) y[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ot][r], h2[u][r], y[ot], 0, 0, 0);
     }
     // y[ot][r] = out[row c][o = 16 ot + 4q + r]
 }
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
 {
     GSTAMP(0);
     extern __shared__ __align__(16) float lds[];
-    using L = Lds<KU, OT>;
+    using L = Lds<KU, OT, (NW > 4)>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
     const int O = OC ? OC : a.net.out_dim;
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
     if ((int64_t)part * NW >= n_tiles) return;         // uniform over the workgroup: safe before the barrier
     float* sd_t = lds + L::END;
-    stage_weights<KU, OT, 64 * NW>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g, MODE == MODE_POLICY ? sd_t : nullptr, KC, OC);
+    stage_weights<KU, OT, 64 * NW, (NW > 4)>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g, MODE == MODE_POLICY ? sd_t : nullptr, KC, OC);
     GSTAMP(1);
     __syncthreads();
 
@@ -855,11 +878,11 @@ int check_gnet(const em_gmlp* net)
     return EM_OK;
 }
 
-size_t lds_bytes(int ku, int ot, bool bwd, bool stage = false)
+size_t lds_bytes(int ku, int ot, bool bwd, bool stage = false, bool v4 = false)
 {
-    const int s1 = (ku * 16 + 2) | 2;
+    const int s1 = v4 ? ku * 16 + 4 : (ku * 16 + 2) | 2, s2 = v4 ? HID + 4 : S2;
     // forward: + sd table of the policy epilogue (16 ot); backward: + transpose scratch and the two loss tables
-    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * ot * S2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 16 * ot) +
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * s2 + 16 * ot * s2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 16 * ot) +
                             (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
 }
 
@@ -885,7 +908,7 @@ int launch_gfwd(const GArgs& ga, hipStream_t s)
     const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(64 * NW);
 #define EM_GF(OT_)                                                                                    \
     case OT_: {                                                                                       \
-        const size_t lds = lds_bytes(5, OT_, false);                                                  \
+        const size_t lds = lds_bytes(5, OT_, false, false, NW > 4);                                   \
         const int rc = set_lds(gmlp_fwd_kernel<5, OT_, MODE, NW>, lds);                               \
         if (rc) return rc;                                                                            \
         hipLaunchKernelGGL((gmlp_fwd_kernel<5, OT_, MODE, NW>), grid, block, lds, s, ga);             \
@@ -893,7 +916,7 @@ int launch_gfwd(const GArgs& ga, hipStream_t s)
     if constexpr (MODE == MODE_POLICY) {
         // the scaled topology's shape (64 servers: 68 inputs, 64 placement logits + the resource share)
         if (ga.net.in_dim == 68 && ga.net.out_dim == 65 && ga.n_place == 64) {
-            const size_t lds = lds_bytes(5, 5, false);
+            const size_t lds = lds_bytes(5, 5, false, false, NW > 4);
             const int rc = set_lds(gmlp_fwd_kernel<5, 5, MODE, NW, 68, 65>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL((gmlp_fwd_kernel<5, 5, MODE, NW, 68, 65>), grid, block, lds, s, ga);

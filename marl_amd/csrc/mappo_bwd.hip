@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "edgemarl.h"
@@ -134,11 +135,35 @@ struct BwdArgs {
 // the LDS transposes and the accumulator drains of one wavefront then run under the other wavefront's MFMAs.  To fit, the
 // layer biases are re-read from LDS per tile instead of living in 32 registers, and the bias gradients are row sums of the
 // transposed dZ tiles that the weight-gradient products stage in LDS anyway (one register per lane instead of 32).
-template <int KU, bool ACTOR, bool STAGE = false>
-__global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const BwdArgs a)
+// SPLIT (STAGE kernels, 512 threads): wavefronts w and w + 4 share a SIMD and a tile sequence.  Wavefront w ("activation")
+// runs the forward pass, the loss, dZ2/dZ1, dW3 and dW2; wavefront w + 4 ("gradient") holds the dW1 accumulators (144 of
+// the critic's 224 accumulator registers, which is what kept the kernel at one wavefront per SIMD), issues the LDS-DMA
+// copies of the pair's input tiles one tile ahead (the by-reference gather's index arithmetic was 2.7 k cycles at the top
+// of every tile) and accumulates dW1 += dZ1^T X for the tile the activation wavefront finished last, from the transposed
+// dZ1 in the pair's scratch and the staged input tile.  Its 16 x KU MFMAs per tile have no dependence on the activation
+// wavefront's current tile, so they fill the matrix pipe while that one waits for LDS, evaluates the loss or drains
+// accumulators.  Three counters per pair in LDS order the hand-overs (tiles staged, dZ1 published, dZ1 read); per
+// accumulator the sums are taken in the same order as in the one-wavefront kernel, so the gradients are bitwise the same.
+#ifdef EM_STAMP_BWD   // cycles per phase of the activation wavefront (workgroup 1, wavefront 0), summed over its tiles
+__device__ unsigned long long bwd_stamps[2][16];
+#define BSTAMP(i)                                                                                        \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if ((i) > 0) bst_acc[i] += (unsigned)(now_ - bst_prev);                                          \
+        else bst_acc[0] += 1;                                                                            \
+        bst_prev = now_;                                                                                 \
+    } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+template <int KU, bool ACTOR, bool STAGE = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const BwdArgs a)
 {
+    static_assert(!SPLIT || STAGE, "the gradient wavefront reads the staged input tile");
     extern __shared__ __align__(16) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NT = SPLIT ? 512 : 256;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;   // wave: the pair's index (LDS regions, tiles, slab row)
+    const bool grad_wave = SPLIT && (threadIdx.x >> 8) != 0;
     const int q = lane >> 4, c = lane & 15;
     const int K1 = a.net.in_dim, O = a.net.out_dim;
     constexpr int K1P = KU * 16;
@@ -155,14 +180,39 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
     // (Reading X[b][i] back from global memory in that product put an L2/HBM round trip in front of its MFMAs.)
     float* xtr = Bs + 2 * HID + 4 * (HID * TS) + wave * (K1P * TS);
 
-    for (int i = threadIdx.x; i < HID * K1P; i += 256) {
+    // SPLIT: {input tiles staged, -, dZ1 published, dZ1 read} counters of the pair, in tiles
+    int* const flg = reinterpret_cast<int*>(Bs + 2 * HID + 4 * (HID * TS) + 4 * (2 * XBUF)) + 4 * wave;
+    enum { F_XREADY = 0, F_READY = 2, F_SDONE = 3 };
+    if (SPLIT && threadIdx.x < 16) reinterpret_cast<int*>(Bs + 2 * HID + 4 * (HID * TS) + 4 * (2 * XBUF))[threadIdx.x] = 0;
+
+    for (int i = threadIdx.x; i < HID * K1P; i += NT) {
         const int r = i / K1P, k = i - r * K1P;
         W1s[r * S1 + k] = k < K1 ? a.net.w1[r * K1 + k] : 0.0f;
     }
-    for (int i = threadIdx.x; i < HID * HID; i += 256) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
-    for (int i = threadIdx.x; i < 16 * HID; i += 256) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
+    for (int i = threadIdx.x; i < HID * HID; i += NT) W2s[(i >> 6) * S2 + (i & 63)] = a.net.w2[i];
+    for (int i = threadIdx.x; i < 16 * HID; i += NT) W3s[(i >> 6) * S2 + (i & 63)] = (i >> 6) < O ? a.net.w3[i] : 0.0f;
     if (threadIdx.x < 2 * HID) Bs[threadIdx.x] = threadIdx.x < HID ? a.net.b1[threadIdx.x] : a.net.b2[threadIdx.x - HID];
     __syncthreads();
+
+    // hand-over waits.  Every wavefront of the workgroup is resident and both wavefronts of a pair walk the same tile
+    // sequence, so each wait is answered; the spin is bounded all the same (a wait that runs out poisons the loss with NaN
+    // and every later wait of the wavefront falls through), so that the grid always drains.
+    bool poisoned = false;
+    unsigned spin_acc[4] = {0, 0, 0, 0}; (void)spin_acc;
+    auto wait_flag = [&](int idx, int want) {
+        if (poisoned) return;
+        int spins = 0;
+        while (__hip_atomic_load(flg + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { poisoned = true; break; }
+        }
+#ifdef EM_STAMP_BWD
+        spin_acc[idx] += (unsigned)spins;
+#endif
+    };
+    auto post_flag = [&](int idx, int value) {
+        if (lane == 0) __hip_atomic_store(flg + idx, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     f32x4 bias3;
 #pragma unroll
@@ -273,6 +323,83 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory", "m0");
         }
     };
+    if constexpr (SPLIT) {
+        if (grad_wave) {
+            // ---- gradient wavefront: stages the pair's input tiles (one ahead of the activation wavefront) and accumulates
+            //      dW1[j][i] += sum_b dZ1^T[j][b] X[b][i] and the layer-1 bias gradient, tile by tile -------------------------
+            f32x4 gw[4][KU];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < KU; ++u) gw[t][u] = zero4;
+            float gb1 = 0.0f;
+#ifdef EM_STAMP_BWD
+            if (blockIdx.x == 1 && (threadIdx.x & 255) == 0) bwd_stamps[ACTOR][15] = 100 + __builtin_amdgcn_s_getreg(2308);   // SIMD id
+#endif
+            const float* const rrow = scr + c * TS + q;
+            const float* const rsum = scr + lane * TS;
+            const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+            float xv[4][KU];
+            auto read_x = [&](int64_t tile_, const float* xt) {     // this lane's dW1 operands of a staged tile
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t rb = tile_ * 16 + 4 * s + q;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const int i = 16 * u + c;
+                        xv[s][u] = (rb < a.n_rows && i < K1) ? xt[(4 * s + q) * K1 + i] : 0.0f;
+                    }
+                }
+            };
+            if (t0 < n_tiles) stage(t0, xs, tile_rows(t0));
+            int rows_nx = tile_rows(t0 + tile_stride);
+            __builtin_amdgcn_s_waitcnt(0);
+            post_flag(F_XREADY, 1);
+            int k = 0, curg = 0;
+            for (int64_t tile = t0; tile < n_tiles; tile += tile_stride, ++k, curg ^= 1) {
+                // the other half held tile k - 1: the activation wavefront finished that tile (F_READY >= k was seen in the
+                // previous iteration) and this wavefront's copies of its values were consumed by the products
+                if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (curg ^ 1) * XBUF, rows_nx);
+                rows_nx = tile_rows(tile + 2 * tile_stride);
+                read_x(tile, xs + curg * XBUF);
+                __builtin_amdgcn_s_waitcnt(0);            // the next tile has landed (and this tile's values are in registers)
+                post_flag(F_XREADY, k + 2);
+                wait_flag(F_READY, k + 1);                // the activation wavefront has finished tile k
+                float tr_c[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tr_c[t][s] = rrow[16 * t * TS + 4 * s];
+                float pb0 = 0.0f, pb1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) { pb0 += rsum[j]; pb1 += rsum[j + 1]; }
+                gb1 += pb0 + pb1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                post_flag(F_SDONE, k + 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            gw[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_c[t][s], xv[s][u], gw[t][u], 0, 0, 0);
+            }
+            float* out = a.slab + ((int64_t)blockIdx.x * 4 + wave) * a.slab_stride;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * q + r;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const int i = 16 * u + c;
+                        if (i < K1) out[j * K1 + i] = poisoned ? __builtin_nanf("") : gw[t][u][r];
+                    }
+                }
+            out[HID * K1 + lane] = gb1;
+            return;
+        }
+    }
     // critic: a state's entry range {k, first} is fetched one tile ahead, so that its returns can be requested at the top of
     // the tile; they are consumed after the forward pass, which hides both HBM round trips (they were exposed: the loss read
     // ent_ret[first + j] right where it needed it, with a single wavefront per SIMD)
@@ -284,8 +411,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         if (r0 < a.n_rows && q == 0) { n_k = a.st_k[r0]; n_first = a.st_first[r0]; }
     }
     int cur = 0;
+    int kt = 0;                                           // SPLIT: tiles this pair has started
     int rows_next = 0;                                    // row numbers of the tile that the NEXT iteration stages
-    if constexpr (STAGE) {
+    if constexpr (STAGE && !SPLIT) {
         const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
         if (t0 < n_tiles) stage(t0, xs, tile_rows(t0));
         rows_next = tile_rows(t0 + tile_stride);
@@ -293,13 +421,21 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    unsigned long long bst_prev = 0; (void)bst_prev;
+    unsigned bst_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)bst_acc;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
+        BSTAMP(0);
         const int64_t row = tile * 16 + c;
         const bool valid = row < a.n_rows;
         const float* xt = xs + cur * XBUF;            // STAGE: this tile, [16][K1] packed
         if constexpr (STAGE) {
-            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF, rows_next);
-            rows_next = tile_rows(tile + 2 * tile_stride);
+            if constexpr (SPLIT) {
+                wait_flag(F_XREADY, kt + 1);          // staged by the gradient wavefront, one tile ahead
+                BSTAMP(9);
+            } else {
+                if (tile + tile_stride < n_tiles) stage(tile + tile_stride, xs + (cur ^ 1) * XBUF, rows_next);
+                rows_next = tile_rows(tile + 2 * tile_stride);
+            }
         } else if constexpr (!PREFETCH) load_x(tile, xb);
         // loss inputs of this tile: issued now, needed after the forward pass
         float p_act[4] = {0.f, 0.f, 0.f, 0.f}, p_adv = 0.0f, p_old = 0.0f;
@@ -322,6 +458,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
             for (int j = 0; j < KPRE; ++j) p_ret[j] = j < p_k ? a.ent_ret[p_first + j] : 0.0f;
         }
+        BSTAMP(1);
         // ---- forward (recompute) -------------------------------------------------------------------
         f32x4 h1[4], h2[4], y;
         int boff = 4 * q;                             // opaque to the optimiser: the bias reads stay inside the loop
@@ -452,6 +589,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             EM_SB();
         }
 
+        BSTAMP(2);
         // ---- loss and dL/dy in accumulator layout: dy[r] = d/d out[row c][o = 4q + r] --------------
         f32x4 dy = zero4;
         if constexpr (ACTOR) {
@@ -514,6 +652,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             }
         }
 
+        BSTAMP(3);
         // ---- backward through layer 3 and 2 ----------------------------------------------------------
         // The weight-gradient products below need their operands with the batch index on the reduction axis: one
         // 64 x 16 transpose per operand through the per-wavefront LDS scratch.  Done where they are needed, each transpose
@@ -556,6 +695,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             else if (i < 24) wcol[(16 * ((i - 8) >> 2) + ((i - 8) & 3)) * TS] = h2[(i - 8) >> 2][(i - 8) & 3];
             else tr_b[(i - 24) >> 2][(i - 24) & 3] = rrow[16 * ((i - 24) >> 2) * TS + 4 * ((i - 24) & 3)];
         };
+        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
 #pragma unroll
         for (int u = 0; u < 4; ++u) {      // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
 #pragma unroll
@@ -580,6 +720,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
         }
 
+        BSTAMP(4);
         // ---- weight gradients: reduction over the 16 batch rows of the tile ---------------------------
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]; dZ2 leaves for the scratch between its MFMAs
 #pragma unroll
@@ -607,6 +748,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         row_sum(gb2_l);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        BSTAMP(5);
         // H1 (its last use above was the ReLU mask of dZ1)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -620,6 +762,7 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
             for (int s = 0; s < 4; ++s) tr_b[t][s] = rrow[16 * t * TS + 4 * s];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        BSTAMP(6);
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]; dZ1 is transposed (and row-summed: gb1) between the batches
         float pb0 = 0.0f, pb1 = 0.0f;
         auto opC = [&](int i) {                         // 48 LDS instructions: dZ1 out, tr_c back, 16 row-sum reads
@@ -638,14 +781,25 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     for (int t1 = 0; t1 < 4; ++t1)
                         gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
                 EM_SB();
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) opC(6 * (2 * s + hh) + i);
+                    for (int i = 0; i < 2; ++i) opC(2 * (2 * s + hh) + i);      // dZ1 out only: the gradient wavefront reads it
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) opC(6 * (2 * s + hh) + i);
+                }
                 EM_SB();
             }
         }
         gb1_l += pb0 + pb1;
 #undef EM_SB
+        if constexpr (SPLIT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            post_flag(F_READY, kt + 1);
+            ++kt;
+        }
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
+        if constexpr (!SPLIT)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
@@ -661,14 +815,24 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
                     gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_c[t][s], xv, gW1[t][u], 0, 0, 0);
             }
         }
-        if constexpr (STAGE) {                        // the next tile has landed; this tile's half may be overwritten
+        BSTAMP(7);
+        if constexpr (STAGE && !SPLIT) {              // the next tile has landed; this tile's half may be overwritten
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            cur ^= 1;
         }
+        if constexpr (STAGE) cur ^= 1;
+        BSTAMP(8);
     }
 
+#ifdef EM_STAMP_BWD
+    if (blockIdx.x == 1 && threadIdx.x == 0)
+    {
+        for (int i = 0; i < 10; ++i) bwd_stamps[ACTOR][i] += bst_acc[i];
+        for (int i = 0; i < 4; ++i) bwd_stamps[ACTOR][10 + i] += spin_acc[i];
+        bwd_stamps[ACTOR][14] = 100 + __builtin_amdgcn_s_getreg(2308);
+    }
+#endif
     // ---- write this wavefront's slab row: [w1 | b1 | w2 | b2 | w3 | b3 | (log_std) | loss, aux, count] ----
     float* out = a.slab + ((int64_t)blockIdx.x * 4 + wave) * a.slab_stride;
     const int o_b1 = HID * K1, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID, o_w3 = o_b2 + HID, o_b3 = o_w3 + O * HID;
@@ -678,10 +842,12 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * q + r;
+            if constexpr (!SPLIT) {
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const int i = 16 * u + c;
-                if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+                for (int u = 0; u < KU; ++u) {
+                    const int i = 16 * u + c;
+                    if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+                }
             }
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
@@ -705,8 +871,9 @@ __global__ __launch_bounds__(256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const 
         loss_sum += __shfl_xor(loss_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
-    out[o_b1 + lane] = gb1_l;
+    if constexpr (!SPLIT) out[o_b1 + lane] = gb1_l;
     out[o_b2 + lane] = gb2_l;
+    if (poisoned) loss_sum = __builtin_nan("");
     if (c == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -805,21 +972,28 @@ int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
     const size_t lds = sizeof(float) * ((size_t)HID * s1 + (size_t)HID * S2 + 16 * S2 + 2 * HID + 4 * HID * TS +
                                         (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0) +
                                         (ku <= 4 ? 4 * (size_t)ku * 16 * TS : 0));
-    const dim3 grid((unsigned)(n_waves / 4)), block(256);
-#define EM_BWD_ONE(KU_, STAGE_)                                                                                   \
+    // two wavefronts per SIMD with the dW1 accumulators in the second one (SPLIT, see mlp3_bwd_kernel); EM_BWD_SPLIT=0 keeps
+    // the one-wavefront kernel (tests compare the two bit for bit)
+    const char* split_env = getenv("EM_BWD_SPLIT");
+    const bool split = stage && !(split_env && split_env[0] == '0');
+    const dim3 grid((unsigned)(n_waves / 4)), block(split ? 512 : 256);
+    const size_t lds_all = lds + (split ? 64 : 0);
+#define EM_BWD_ONE(KU_, STAGE_, SPLIT_)                                                                           \
     {                                                                                                             \
-        if (lds > 64 * 1024) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute((const void*)mlp3_bwd_kernel<KU_, ACTOR, STAGE_>,                   \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        if (lds_all > 64 * 1024) {                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)mlp3_bwd_kernel<KU_, ACTOR, STAGE_, SPLIT_>,           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);         \
             if (e != hipSuccess) return em::hip_fail(e, "hipFuncSetAttribute");                                   \
         }                                                                                                         \
-        hipLaunchKernelGGL((mlp3_bwd_kernel<KU_, ACTOR, STAGE_>), grid, block, lds, s, ba);                       \
+        hipLaunchKernelGGL((mlp3_bwd_kernel<KU_, ACTOR, STAGE_, SPLIT_>), grid, block, lds_all, s, ba);           \
     }
 #define EM_BWD(KU_)                                                                                               \
     case KU_: {                                                                                                   \
         if constexpr (KU_ > 4) {                                                                                  \
-            if (stage) EM_BWD_ONE(KU_, true) else EM_BWD_ONE(KU_, false)                                          \
-        } else EM_BWD_ONE(KU_, false)                                                                             \
+            if (split) EM_BWD_ONE(KU_, true, true)                                                                \
+            else if (stage) EM_BWD_ONE(KU_, true, false)                                                          \
+            else EM_BWD_ONE(KU_, false, false)                                                                    \
+        } else EM_BWD_ONE(KU_, false, false)                                                                      \
     } break
     switch (ku) {
         EM_BWD(1); EM_BWD(2); EM_BWD(3); EM_BWD(4); EM_BWD(5); EM_BWD(6); EM_BWD(7); EM_BWD(8); EM_BWD(9);
@@ -833,6 +1007,13 @@ int launch_bwd(const BwdArgs& ba, int64_t n_waves, hipStream_t s)
 }  // namespace
 
 extern "C" {
+#ifdef EM_STAMP_BWD
+int em_debug_bwd_stamps(unsigned long long* out, int reset)
+{
+    if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bwd_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bwd_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 int em_gae(const em_rollout* ro, double gamma, double lam, double* partials, int64_t partials_capacity, double* moments3,
            void* stream)

@@ -202,6 +202,31 @@ def test_states_by_reference_equal_compact_copies():
         assert torch.equal(a[k], b[k]), k
 
 
+def test_two_wavefront_critic_backward_equals_the_one_wavefront_kernel(monkeypatch):
+    """mlp3_bwd_kernel's SPLIT variant (the dW1 accumulators in a second wavefront per SIMD, hand-overs through LDS counters)
+    takes every partial sum in the order of the one-wavefront kernel: same episode, same update, same parameters bit for bit,
+    by reference (scattered state rows) and with compact copies, over several tiles per wavefront pair."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.mappo import RolloutStorage
+    from marl_amd.trainer import MAPPOTrainer
+    cfg = dict(ENV_CONFIG, episode_length=120)
+    B = 1500
+    for by_ref in (True, False):
+        outs = []
+        for split in ("1", "0"):
+            monkeypatch.setenv("EM_BWD_SPLIT", split)
+            tr = MAPPOTrainer(cfg, seed=9, device="cuda:0", n_envs=B, verbose=False)
+            if not by_ref:
+                tr.mappo.buffer = tr._train_storage = RolloutStorage(B, 10, 120, tr.device, by_reference=False)
+            for _ in range(2):                   # the second update starts from parameters the first one produced
+                tr.train_episode(explore=True, record_buffer=True)
+                out = tr.mappo.update()
+            outs.append((tr.mappo.flat_params.clone(), out))
+        (pa, oa), (pb, ob) = outs
+        assert np.isfinite(oa["critic_loss"]) and oa == ob, (oa, ob)
+        assert torch.equal(pa, pb)
+
+
 @pytest.mark.parametrize("n_envs,explore,n_nodes", [(700, True, 10), (700, False, 10), (5, True, 10), (4099, True, 10),
                                                     (300, True, 6), (300, True, 8), (300, True, 2)])
 def test_one_launch_index_and_policy_equals_the_two_launches(n_envs, explore, n_nodes):
