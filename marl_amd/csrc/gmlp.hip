@@ -16,11 +16,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "edgemarl.h"
 #include "em_common.h"
 #include "em_policy_math.h"
+
+#ifndef EM_GBWD_SPLIT_ACTOR
+#define EM_GBWD_SPLIT_ACTOR 0   // the 65-output actor does not fit 256 registers beside dW2 and dW3
+#endif
 
 namespace {
 
@@ -385,19 +390,26 @@ extern "C" int em_debug_gfwd_stamps(unsigned long long* out) { return (int)hipMe
 // in between (global_load_lds_dwordx4), into a per-wavefront double buffer while the previous tile computes; the forward
 // takes its x fragments from the copy and the dW1 products read it again (the register version gathered 4 x KU dependent
 // scalars per tile from global memory a second time, through the permutation).
-template <int KU, int OT, bool ACTOR, bool STAGE = false>
-__global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
+// SPLIT (STAGE kernels, 512 threads; mlp3_bwd_kernel in mappo_bwd.hip has the long version): wavefronts w and w + 4 share a
+// SIMD and a tile sequence.  Wavefront w runs forward, loss, dZ2/dZ1, dW3 and dW2; wavefront w + 4 stages the pair's input
+// tiles one ahead, holds the dW1 accumulators and the layer-1 bias gradient and issues dW1 += dZ1^T X as one dense run of
+// register-operand MFMAs per tile.  Three LDS counters per pair order the hand-overs; the sums of every accumulator are taken
+// in the order of the one-wavefront kernel.
+template <int KU, int OT, bool ACTOR, bool STAGE = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GArgs a)
 {
+    static_assert(!SPLIT || STAGE, "the gradient wavefront reads the staged input tile");
     extern __shared__ __align__(16) float lds[];
     using L = Lds<KU, OT>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;   // wave: the pair's index (LDS regions, tiles, slab row)
+    const bool grad_wave = SPLIT && (threadIdx.x >> 8) != 0;
     const int q = lane >> 4, c = lane & 15;
     const int K1 = a.net.in_dim, O = a.net.out_dim;
     const int g = blockIdx.x / a.split, part = blockIdx.x - g * a.split;
     const int64_t r0 = a.group_off ? a.group_off[g] : 0, r1 = a.group_off ? a.group_off[g + 1] : a.n_rows;
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
     float* scr = lds + L::END + wave * (HID * TS);     // per-wavefront transpose scratch [64][TS]
-    stage_weights<KU, OT>(lds, a.net, ACTOR ? a.log_std : nullptr, g);
+    stage_weights<KU, OT, SPLIT ? 512 : 256>(lds, a.net, ACTOR ? a.log_std : nullptr, g);
     // per-output constants of the Gaussian log-density, evaluated once per workgroup instead of three exp() and a
     // reciprocal per element and tile: 2*sd^2 and 1/sd^2 (same expressions, so the same bits as evaluating them in place)
     float* den_t = lds + L::END + 4 * (HID * TS);
@@ -405,7 +417,26 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
     constexpr int NI = (4 * L::K1P + 63) / 64;        // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
     constexpr int XBUF = NI * 256;                    // floats per staged tile (the tail of the last copy is slack)
     float* xs = iv_t + 16 * OT + wave * (2 * XBUF);
+    // SPLIT: {input tiles staged, -, dZ1 published, dZ1 read} counters of the pair, in tiles
+    int* const flg_all = reinterpret_cast<int*>(iv_t + 16 * OT + 4 * (2 * XBUF));
+    int* const flg = flg_all + 4 * wave;
+    enum { F_XREADY = 0, F_READY = 2, F_SDONE = 3 };
+    if (SPLIT && threadIdx.x < 16) flg_all[threadIdx.x] = 0;
     __syncthreads();
+    // hand-over waits: bounded (a wait that runs out poisons the result with NaN and later waits fall through), so that the
+    // grid drains whatever happens
+    bool poisoned = false;
+    auto wait_flag = [&](int idx, int want) {
+        if (poisoned) return;
+        int spins = 0;
+        while (__hip_atomic_load(flg + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { poisoned = true; break; }
+        }
+    };
+    auto post_flag = [&](int idx, int value) {
+        if (lane == 0) __hip_atomic_store(flg + idx, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     if constexpr (ACTOR) {
         if (threadIdx.x < 16 * OT) {
             const float sd = expf(lds[L::LS + threadIdx.x]);
@@ -480,8 +511,72 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
     };
     int cur = 0;
     const int64_t tile_stride = (int64_t)a.split * 4;
+    if constexpr (SPLIT) {
+        if (grad_wave) {
+            float gb1 = 0.0f;
+            const int64_t t0 = (int64_t)part * 4 + wave;
+            int64_t g_next = global_row(t0 + tile_stride);
+            if (t0 < n_tiles) stage(t0, global_row(t0), xs);
+            __builtin_amdgcn_s_waitcnt(0);
+            post_flag(F_XREADY, 1);
+            int k = 0, curg = 0;
+            for (int64_t tile = t0; tile < n_tiles; tile += tile_stride, ++k, curg ^= 1) {
+                // the other half held tile k - 1: its forward pass is over (F_READY >= k was seen) and this wavefront's copies
+                // of its values were consumed by the products
+                if (tile + tile_stride < n_tiles) stage(tile + tile_stride, g_next, xs + (curg ^ 1) * XBUF);
+                g_next = global_row(tile + 2 * tile_stride);
+                const float* xt = xs + curg * XBUF;
+                float xv[4][KU];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool vb = tile * 16 + 4 * s + q < n_rows;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const int i = 16 * u + c;
+                        xv[s][u] = (vb && i < K1) ? xt[(4 * s + q) * K1 + i] : 0.0f;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);            // the next tile has landed (and this tile's values are in registers)
+                post_flag(F_XREADY, k + 2);
+                wait_flag(F_READY, k + 1);                // the activation wavefront has finished tile k
+                float tr[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tr[t][s] = scr[(16 * t + c) * TS + 4 * s + q];
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) { p0 += scr[lane * TS + j]; p1 += scr[lane * TS + j + 1]; }
+                gb1 += p0 + p1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                post_flag(F_SDONE, k + 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[t][s], xv[s][u], gW1[t][u], 0, 0, 0);
+            }
+            float* out = a.slab + (((int64_t)g * a.split + part) * 4 + wave) * a.slab_stride;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * q + r;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const int i = 16 * u + c;
+                        if (i < K1) out[j * K1 + i] = poisoned ? __builtin_nanf("") : gW1[t][u][r];
+                    }
+                }
+            out[HID * K1 + lane] = gb1;
+            return;
+        }
+    }
+    int kt = 0;                                        // SPLIT: tiles this pair has started
     int64_t grow_cur = global_row((int64_t)part * 4 + wave), grow_next = global_row((int64_t)part * 4 + wave + tile_stride);
-    if constexpr (STAGE) {
+    if constexpr (STAGE && !SPLIT) {
         const int64_t t0 = (int64_t)part * 4 + wave;
         if (t0 < n_tiles) stage(t0, grow_cur, xs);
         __builtin_amdgcn_s_waitcnt(0);
@@ -496,7 +591,8 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         const float* xt = xs + cur * XBUF;
         float xb[KU * 4];
         if constexpr (STAGE) {
-            if (tile + tile_stride < n_tiles) stage(tile + tile_stride, grow_next, xs + (cur ^ 1) * XBUF);
+            if constexpr (SPLIT) wait_flag(F_XREADY, kt + 1);      // staged by the gradient wavefront, one tile ahead
+            else if (tile + tile_stride < n_tiles) stage(tile + tile_stride, grow_next, xs + (cur ^ 1) * XBUF);
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int k0 = 16 * u + 4 * q;
@@ -648,6 +744,7 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
             __builtin_amdgcn_wave_barrier();
         };
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
+        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
         transpose64(h2, tr_b, nullptr);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
@@ -677,6 +774,15 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                 for (int t1 = 0; t1 < 4; ++t1)
                     gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
+        if constexpr (SPLIT) {                        // dZ1^T to the scratch; the gradient wavefront takes it from there
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = dz1[t][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            post_flag(F_READY, kt + 1);
+            ++kt;
+        } else {
         transpose64(dz1, tr_a, &gb1_l);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -698,12 +804,13 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
                     gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t][s], xv, gW1[t][u], 0, 0, 0);
             }
         }
-        if constexpr (STAGE) {                        // the next tile has landed; this tile's half may be overwritten
+        }
+        if constexpr (STAGE && !SPLIT) {              // the next tile has landed; this tile's half may be overwritten
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            cur ^= 1;
         }
+        if constexpr (STAGE) cur ^= 1;
         grow_cur = grow_next;
         grow_next = grow_nn;
     }
@@ -717,10 +824,12 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * q + r;
+            if constexpr (!SPLIT) {
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const int i = 16 * u + c;
-                if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+                for (int u = 0; u < KU; ++u) {
+                    const int i = 16 * u + c;
+                    if (i < K1) out[j * K1 + i] = gW1[t][u][r];
+                }
             }
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
@@ -749,8 +858,9 @@ __global__ __launch_bounds__(256, 1) void gmlp_bwd_kernel(const GArgs a)
         loss_sum += __shfl_xor(loss_sum, m);
         cnt_sum += __shfl_xor(cnt_sum, m);
     }
-    out[o_b1 + lane] = gb1_l;
+    if constexpr (!SPLIT) out[o_b1 + lane] = gb1_l;
     out[o_b2 + lane] = gb2_l;
+    if (poisoned) loss_sum = __builtin_nan("");
     if (c == 0) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
@@ -935,19 +1045,25 @@ template <bool ACTOR>
 int launch_gbwd(const GArgs& ga, hipStream_t s)
 {
     const int ot = (ga.net.out_dim + 15) / 16;
-    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(256);
     // staged input tiles (see gmlp_bwd_kernel): rows of a multiple of four floats on 16-byte boundaries
     const bool stage = (ga.net.in_dim & 3) == 0 && (ga.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(ga.x) & 15) == 0;
-#define EM_GB_ONE(OT_, STAGE_)                                                                        \
+    // two wavefronts per SIMD with the dW1 accumulators in the second one (SPLIT); EM_BWD_SPLIT=0 keeps the one-wavefront
+    // kernel (tests compare the two bit for bit)
+    const char* split_env = getenv("EM_BWD_SPLIT");
+    const bool split2 = stage && (!ACTOR || EM_GBWD_SPLIT_ACTOR) && !(split_env && split_env[0] == '0');
+    const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(split2 ? 512 : 256);
+#define EM_GB_ONE(OT_, STAGE_, SPLIT_)                                                                \
     {                                                                                                 \
-        const size_t lds = lds_bytes(5, OT_, true, STAGE_);                                           \
-        const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_>, lds);                          \
+        const size_t lds = lds_bytes(5, OT_, true, STAGE_) + (SPLIT_ ? 64 : 0);                       \
+        const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_, SPLIT_>, lds);                  \
         if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_>), grid, block, lds, s, ga);        \
+        hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_, SPLIT_>), grid, block, lds, s, ga); \
     }
 #define EM_GB(OT_)                                                                                    \
     case OT_: {                                                                                       \
-        if (stage) EM_GB_ONE(OT_, true) else EM_GB_ONE(OT_, false)                                    \
+        if (split2) EM_GB_ONE(OT_, true, true)                                                        \
+        else if (stage) EM_GB_ONE(OT_, true, false)                                                   \
+        else EM_GB_ONE(OT_, false, false)                                                             \
     } break
     if constexpr (ACTOR) {
         switch (ot) {

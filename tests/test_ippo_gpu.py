@@ -122,3 +122,24 @@ def test_scaled_64x256_smoke_and_eval():
     assert bool(torch.isfinite(tr.algo.actor.flat).all()) and not torch.equal(before, tr.algo.actor.flat)
     ev = tr.evaluate(num_episodes=96)
     assert all(np.isfinite(v) for v in ev.values())
+
+
+def test_two_wavefront_grouped_backward_equals_the_one_wavefront_kernel(monkeypatch):
+    """gmlp_bwd_kernel's SPLIT variant (dW1 and the tile staging in a second wavefront per SIMD) takes every partial sum in the
+    order of the one-wavefront kernel: same episodes, same updates, same parameters bit for bit (many tiles per learner)."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 40
+    for algorithm in ("ippo", "shared"):
+        outs = []
+        for split in ("1", "0"):
+            monkeypatch.setenv("EM_BWD_SPLIT", split)
+            tr = IPPOTrainer(cfg, seed=3, device="cuda:0", n_envs=2048, algorithm=algorithm, verbose=False)
+            for _ in range(2):
+                tr.train_episode(explore=True, record_buffer=True)
+                up = tr.algo.update()
+            outs.append((tr.algo.actor.flat.clone(), tr.algo.critic.flat.clone(), up))
+        (aa, ca, ua), (ab, cb, ub) = outs
+        assert np.isfinite(ua["critic_loss"]) and ua == ub, (ua, ub)
+        assert torch.equal(aa, ab) and torch.equal(ca, cb)
