@@ -24,7 +24,7 @@
 #include "em_policy_math.h"
 
 #ifndef EM_GBWD_SPLIT_ACTOR
-#define EM_GBWD_SPLIT_ACTOR 0   // the 65-output actor does not fit 256 registers beside dW2 and dW3
+#define EM_GBWD_SPLIT_ACTOR 1
 #endif
 
 namespace {
@@ -417,11 +417,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
     constexpr int NI = (4 * L::K1P + 63) / 64;        // wavefront-wide 16-byte copies per tile (16 rows x K1 floats)
     constexpr int XBUF = NI * 256;                    // floats per staged tile (the tail of the last copy is slack)
     float* xs = iv_t + 16 * OT + wave * (2 * XBUF);
-    // SPLIT: {input tiles staged, -, dZ1 published, dZ1 read} counters of the pair, in tiles
+    // SPLIT: {input tiles staged, H2^T/dY^T published, dZ1^T published, dZ1^T read, H2^T/dY^T read} counters of the pair, in
+    // tiles, and the pair's hand-over buffer for dW3's operands: H2^T [64][TS] | dY^T [16 OT][TS]
     int* const flg_all = reinterpret_cast<int*>(iv_t + 16 * OT + 4 * (2 * XBUF));
-    int* const flg = flg_all + 4 * wave;
-    enum { F_XREADY = 0, F_READY = 2, F_SDONE = 3 };
-    if (SPLIT && threadIdx.x < 16) flg_all[threadIdx.x] = 0;
+    int* const flg = flg_all + 8 * wave;
+    enum { F_XREADY = 0, F_READY3 = 1, F_READY = 2, F_SDONE = 3, F_SDONE3 = 4 };
+    constexpr int HB = (HID + 16 * OT) * TS;
+    float* const hb = iv_t + 16 * OT + 4 * (2 * XBUF) + 32 + wave * HB;
+    if (SPLIT && threadIdx.x < 32) flg_all[threadIdx.x] = 0;
     __syncthreads();
     // hand-over waits: bounded (a wait that runs out poisons the result with NaN and later waits fall through), so that the
     // grid drains whatever happens
@@ -538,6 +541,28 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 }
                 __builtin_amdgcn_s_waitcnt(0);            // the next tile has landed (and this tile's values are in registers)
                 post_flag(F_XREADY, k + 2);
+                // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b], as soon as tile k's loss is known
+                wait_flag(F_READY3, k + 1);
+                {
+                    float tb[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) tb[t][s] = hb[(16 * t + c) * TS + 4 * s + q];
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) {
+                        float ty[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) ty[s] = hb[(HID + 16 * ot + c) * TS + 4 * s + q];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                gW3[ot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ty[s], tb[t][s], gW3[ot][t], 0, 0, 0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    post_flag(F_SDONE3, k + 1);
+                }
                 wait_flag(F_READY, k + 1);                // the activation wavefront has finished tile k
                 float tr[4][4];
 #pragma unroll
@@ -571,6 +596,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                     }
                 }
             out[HID * K1 + lane] = gb1;
+            const int o_w3g = HID * K1 + HID + HID * HID + HID;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * ot + 4 * q + r < O) out[o_w3g + (16 * ot + 4 * q + r) * HID + 16 * t + c] = gW3[ot][t][r];
             return;
         }
     }
@@ -687,6 +720,19 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             }
         }
 
+        if constexpr (SPLIT) {                         // dW3's operands to the gradient wavefront
+            wait_flag(F_SDONE3, kt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hb[(16 * t + 4 * q + r) * TS + c] = h2[t][r];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hb[(HID + 16 * ot + 4 * q + r) * TS + c] = dy[ot][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            post_flag(F_READY3, kt + 1);
+        }
         // ---- backward through layers 3 and 2 ------------------------------------------------------------------
         f32x4 dz2[4], dz1[4];
 #pragma unroll
@@ -744,7 +790,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             __builtin_amdgcn_wave_barrier();
         };
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
-        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
+        if constexpr (!SPLIT) {
         transpose64(h2, tr_b, nullptr);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
@@ -763,6 +809,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 for (int t = 0; t < 4; ++t)
                     gW3[ot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[ot][t], 0, 0, 0);
         }
+        }
+        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
         transpose64(dz2, tr_a, &gb2_l);
         transpose64(h1, tr_b, nullptr);
@@ -834,13 +882,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
         }
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+        for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * ot + 4 * q + r < O) out[o_w3 + (16 * ot + 4 * q + r) * HID + 16 * t + c] = gW3[ot][t][r];
+                for (int r = 0; r < 4; ++r)
+                    if (16 * ot + 4 * q + r < O) out[o_w3 + (16 * ot + 4 * q + r) * HID + 16 * t + c] = gW3[ot][t][r];
+    }
     // bias-type gradients: reduce the 16 lanes that share q (fixed butterfly order)
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) {
@@ -1054,7 +1104,7 @@ int launch_gbwd(const GArgs& ga, hipStream_t s)
     const dim3 grid((unsigned)(ga.net.n_groups * ga.split)), block(split2 ? 512 : 256);
 #define EM_GB_ONE(OT_, STAGE_, SPLIT_)                                                                \
     {                                                                                                 \
-        const size_t lds = lds_bytes(5, OT_, true, STAGE_) + (SPLIT_ ? 64 : 0);                       \
+        const size_t lds = lds_bytes(5, OT_, true, STAGE_) + (SPLIT_ ? 128 + 4 * sizeof(float) * (HID + 16 * OT_) * TS : 0); \
         const int rc = set_lds(gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_, SPLIT_>, lds);                  \
         if (rc) return rc;                                                                            \
         hipLaunchKernelGGL((gmlp_bwd_kernel<5, OT_, ACTOR, STAGE_, SPLIT_>), grid, block, lds, s, ga); \
