@@ -368,7 +368,7 @@ class IPPOTrainer:
             a.buffer = self._train_storage
         if record_buffer:
             total_reward = ro.t["reward_tb"][:T].sum(dim=0)
-            if hasattr(a, "compute_values") and self.algorithm != "mappo":
+            if hasattr(a, "compute_values"):
                 a.compute_values()
         metrics = env.episode_metrics()
         mean, p99_missing = summarise_episode_metrics(metrics, env.n_pending > 0)      # mappo_trainer.py:222-231

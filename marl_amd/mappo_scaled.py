@@ -86,15 +86,48 @@ class ScaledMAPPO(IPPO):
                                                  tt["first_tb"][t].data_ptr(), 0.0, 1.0, tt["value_tb"][t].data_ptr(), _stream(dev)),
                            "em_cc_forward")
 
-        if self.overlap_value:
+        defer = self.defer_values and ro.horizon > 1    # one launch over all recorded states at the end (compute_values)
+        if defer:
+            value = lambda: None  # noqa: E731
+        elif self.overlap_value:
             self._value_async(value)
         # shared actor: the step as one group ({0, entries} sits behind the per-decider offsets), same permutation
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
                     tt["ent_action"], tt["ent_logp"], tt["group_off"][D + 1:], tt["perm"], self.split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
-        if not self.overlap_value:
+        if defer or not self.overlap_value:
             value()
         ro.steps_recorded = t + 1
+
+    def _decider_grouping(self, E):
+        """Entries [0, E) grouped by decider (stable: fixed summation order per decider block of the first layer); cached for
+        the (E, steps recorded) it was built for and shared by compute_values() and update()."""
+        ro = self.buffer
+        key = ("decider", E, ro.steps_recorded)
+        if getattr(ro, "group_cache", None) is None or ro.group_cache[0] != key:
+            off, perm = gmlp.group_index(ro.t["ent_agent"][:E], self.D)
+            ro.group_cache = (key, off, perm)
+        return ro.group_cache[1], ro.group_cache[2]
+
+    def compute_values(self):
+        """Deferred mode: the central critic over every recorded state that has no value yet, in one em_cc_forward (nothing
+        in the rollout reads a value before GAE; per step the sparse first layer ran on a side stream beside the policy
+        launch, 61 us a step).  A no-op otherwise."""
+        ro = self.buffer
+        if not (self.defer_values and ro.horizon > 1) or getattr(ro, "values_through", 0) == ro.steps_recorded:
+            return
+        E = ro.total()
+        tt, dev, T, B = ro.t, self.device, ro.steps_recorded, ro.n_envs
+        if E > 0:
+            off, perm = self._decider_grouping(E)
+            cc = self.critic.struct()
+            part = self._partials(E)
+            with torch.cuda.device(dev):
+                _lib.check(self._L.em_cc_forward(C.byref(cc), tt["ent_obs"].data_ptr(), off.data_ptr(), perm.data_ptr(),
+                                                 self.cc_split, part.data_ptr(), T * B, tt["k_tb"].data_ptr(),
+                                                 tt["first_tb"].data_ptr(), 0.0, 1.0, tt["value_tb"].data_ptr(), _stream(dev)),
+                           "em_cc_forward")
+        ro.values_through = ro.steps_recorded
 
     def update(self):
         ro = self.buffer
@@ -103,6 +136,7 @@ class ScaledMAPPO(IPPO):
         if E is None:
             return {}
         tt, L, dev, T, B = ro.t, self._L, self.device, ro.steps_recorded, ro.n_envs
+        self.compute_values()
         # MAPPO.compute_gae over each environment's flattened list (em_gae reads the dense [T][B] arrays)
         g = _lib.EmRollout()
         g.n_envs, g.horizon, g.n_nodes = B, T, self.S
@@ -115,7 +149,7 @@ class ScaledMAPPO(IPPO):
         x = tt["ent_obs"][:E]
         off_a = torch.tensor([0, E], dtype=torch.int64, device=dev)
         if E > 0:
-            off_c, perm_c = gmlp.group_index(tt["ent_agent"][:E], self.D)  # stable: fixed summation order per decider block
+            off_c, perm_c = self._decider_grouping(E)
         cc = self.critic.struct()
         n_states = T * B
         if self._dz is None or self._dz.shape[0] < n_states:
