@@ -72,8 +72,12 @@ class ScaledMAPPO(IPPO):
         ro = self.buffer
         tt, dev, D = ro.t, self.device, self.D
         self.join_value()
+        defer = self.defer_values and ro.horizon > 1    # one launch over all recorded states at the end (compute_values)
+        # the per-decider grouping of a step serves the central critic's sparse first layer only: deferred, the step is
+        # indexed as one group (no histogram, no cursor atomics, identity permutation)
+        ng = 1 if defer else D
         with torch.cuda.device(dev):
-            _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, D, env.n_pending.data_ptr(), env.pend_decider.data_ptr(),
+            _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, ng, env.n_pending.data_ptr(), env.pend_decider.data_ptr(),
                                                  env.pend_obs.data_ptr(), _stream(dev)), "ems_rollout_index")
         cc = self.critic.struct()
         B = ro.n_envs
@@ -86,14 +90,13 @@ class ScaledMAPPO(IPPO):
                                                  tt["first_tb"][t].data_ptr(), 0.0, 1.0, tt["value_tb"][t].data_ptr(), _stream(dev)),
                            "em_cc_forward")
 
-        defer = self.defer_values and ro.horizon > 1    # one launch over all recorded states at the end (compute_values)
         if defer:
             value = lambda: None  # noqa: E731
         elif self.overlap_value:
             self._value_async(value)
         # shared actor: the step as one group ({0, entries} sits behind the per-decider offsets), same permutation
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
-                    tt["ent_action"], tt["ent_logp"], tt["group_off"][D + 1:], tt["perm"], self.split, noise=noise, explore=explore,
+                    tt["ent_action"], tt["ent_logp"], tt["group_off"][(D + 1 if ng > 1 else 0):], tt["perm"], self.split, noise=noise, explore=explore,
                     seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
         if defer or not self.overlap_value:
             value()
