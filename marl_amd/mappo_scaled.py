@@ -57,7 +57,9 @@ class ScaledMAPPO(IPPO):
         self.g_critic = torch.zeros((1, nc), dtype=torch.float32, device=dev)
         self.m_c, self.v_c = torch.zeros_like(self.critic.flat), torch.zeros_like(self.critic.flat)
         self.grads = torch.zeros((1, self.actor.n_per + 3 + nc + 3), dtype=torch.float32, device=dev)
-        self.cc_split = 1 if self.D >= 64 else max(1, 256 // self.D)
+        # workgroups per decider block of the sparse first layer: two per CU (their waits for the scattered rows overlap;
+        # one took 257 instead of 227 ms per update at 256 deciders)
+        self.cc_split = max(1, 512 // self.D)
         self.moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._gae_partials = torch.zeros(3 * ((int(n_envs) + 255) // 256), dtype=torch.float64, device=dev)
         self._partial = self._dz = self._cc_slab = None

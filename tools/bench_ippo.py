@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--shared", action="store_true")
     ap.add_argument("--fwd-split", type=int, default=0)
     ap.add_argument("--bwd-split", type=int, default=0)
+    ap.add_argument("--cc-split", type=int, default=0)
     ap.add_argument("--algorithm", default="ippo", choices=["ippo", "shared", "mappo"])
     a = ap.parse_args()
     cfg = dict(SCALED_ENV_CONFIG)
@@ -27,6 +28,9 @@ def main():
     tr.overlap_value = not a.no_overlap
     if a.fwd_split:
         tr.algo.fwd_split = a.fwd_split
+    if a.cc_split:
+        tr.algo.cc_split = a.cc_split
+        tr.algo._cc_slab = None
     if a.bwd_split:
         tr.algo.split = a.bwd_split
         tr.algo._slab_a = tr.algo._slab_c = None
