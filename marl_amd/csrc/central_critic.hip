@@ -87,12 +87,23 @@ __global__ __launch_bounds__(256) void cc_l1_fwd_kernel(const CCArgs a)
         W1s[r * S1 + k] = k < W ? w1[(int64_t)r * a.net.ldw + k] : 0.0f;
     }
     __syncthreads();
-    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
-        const int64_t row = tile * 16 + c;
-        const bool valid = row < n_rows;
-        const int64_t e = valid ? (int64_t)a.perm[r0 + row] : 0;
-        float xb[KU * 4];
-        load_obs_frag(a.ent_obs, W, e, valid, q, xb);
+    // Two dependent memory round trips feed a tile (permutation, then the scattered observation row) and one or two
+    // wavefronts per SIMD hide neither: the entry numbers are requested two tiles ahead and the rows one tile ahead, so that
+    // a tile's 80 MFMAs never wait for memory (10 ms -> 4 ms per launch over 36.7 M entries together with two workgroups
+    // per decider).
+    const int64_t stride = (int64_t)a.split * 4;
+    auto entry_of = [&](int64_t tl) -> int32_t {
+        const int64_t row = tl * 16 + c;
+        return (tl < n_tiles && row < n_rows) ? a.perm[r0 + row] : -1;
+    };
+    int64_t tile = (int64_t)part * 4 + wave;
+    int32_t e0 = entry_of(tile), e1 = entry_of(tile + stride);
+    float xb[KU * 4];
+    load_obs_frag(a.ent_obs, W, e0 < 0 ? 0 : e0, e0 >= 0, q, xb);
+    for (; tile < n_tiles; tile += stride) {
+        const int32_t e2 = entry_of(tile + 2 * stride);
+        float xn[KU * 4];
+        load_obs_frag(a.ent_obs, W, e1 < 0 ? 0 : e1, e1 >= 0, q, xn);
         f32x4 h[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -102,11 +113,14 @@ __global__ __launch_bounds__(256) void cc_l1_fwd_kernel(const CCArgs a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h[t], 0, 0, 0);
         }
-        if (valid) {
-            float4* dst = reinterpret_cast<float4*>(a.P + e * HID);
+        if (e0 >= 0) {
+            float4* dst = reinterpret_cast<float4*>(a.P + (int64_t)e0 * HID);
 #pragma unroll
             for (int t = 0; t < 4; ++t) dst[4 * t + q] = make_float4(h[t][0], h[t][1], h[t][2], h[t][3]);   // j = 16t + 4q + r
         }
+        e0 = e1; e1 = e2;
+#pragma unroll
+        for (int s = 0; s < KU * 4; ++s) xb[s] = xn[s];
     }
 }
 
@@ -192,11 +206,22 @@ __global__ __launch_bounds__(256) void cc_head_fwd_kernel(const CCArgs a)
     stage_head(lds, a.net);
     __syncthreads();
     const int64_t n_tiles = (a.n_states + 15) >> 4;
+    // a state's {entries, first entry} one tile ahead: the gather's row addresses are then known at the top of the tile
+    int k_n = 0, first_n = 0;
+    {
+        const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+        if (s0 < a.n_states) { k_n = (int)a.k_arr[s0]; first_n = a.first_arr[s0]; }
+    }
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t s = tile * 16 + c;
         const bool valid = s < a.n_states;
-        const int k = valid ? (int)a.k_arr[s] : 0;
-        const int64_t first = valid ? (int64_t)a.first_arr[s] : 0;
+        const int k = k_n;
+        const int64_t first = first_n;
+        k_n = 0;
+        {
+            const int64_t sn = s + (int64_t)gridDim.x * 64;
+            if (sn < a.n_states) { k_n = (int)a.k_arr[sn]; first_n = a.first_arr[sn]; }
+        }
         f32x4 h1[4], h2[4], y;
         gather_h1(a, lds, k, first, q, h1);
         head_forward(lds, q, c, h1, h2, y);
@@ -227,11 +252,22 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
         gW3[t] = zero4; gb1[t] = zero4; gb2[t] = zero4;
     }
     const int64_t n_tiles = (a.n_states + 15) >> 4;
+    // a state's {entries, first entry} one tile ahead: the gather's row addresses are then known at the top of the tile
+    int k_n = 0, first_n = 0;
+    {
+        const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+        if (s0 < a.n_states) { k_n = (int)a.k_arr[s0]; first_n = a.first_arr[s0]; }
+    }
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t s = tile * 16 + c;
         const bool valid = s < a.n_states;
-        const int k = valid ? (int)a.k_arr[s] : 0;
-        const int64_t first = valid ? (int64_t)a.first_arr[s] : 0;
+        const int k = k_n;
+        const int64_t first = first_n;
+        k_n = 0;
+        {
+            const int64_t sn = s + (int64_t)gridDim.x * 64;
+            if (sn < a.n_states) { k_n = (int)a.k_arr[sn]; first_n = a.first_arr[sn]; }
+        }
         f32x4 h1[4], h2[4], y;
         gather_h1(a, lds, k, first, q, h1);
         head_forward(lds, q, c, h1, h2, y);
@@ -373,24 +409,60 @@ __global__ __launch_bounds__(256) void cc_l1_bwd_kernel(const CCArgs a)
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < KU; ++u) gW1[t][u] = zero4;
-    for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += (int64_t)a.split * 4) {
+    // Three dependent round trips feed a tile (permutation -> state of the entry -> dZ1 row; the observation row hangs off
+    // the first): entry numbers three tiles ahead, their states two, the operand values one, so the 80 MFMAs of a tile
+    // find their operands in registers.
+    const int64_t stride = (int64_t)a.split * 4;
+    auto entries_of = [&](int64_t tl, int32_t (&e)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int64_t rb = tile * 16 + 4 * s + q;          // batch index on the reduction axis
-            const bool vb = rb < n_rows;
-            const int64_t e = vb ? (int64_t)a.perm[r0 + rb] : 0;
-            const int64_t st = vb ? (int64_t)a.ent_state[e] : 0;
-            const float* dz = a.DZ + st * HID;
-            const float* xrow = a.ent_obs + e * W;
-            float av[4], xv[KU];
+            const int64_t rb = tl * 16 + 4 * s + q;            // batch index on the reduction axis
+            e[s] = (tl < n_tiles && rb < n_rows) ? a.perm[r0 + rb] : -1;
+        }
+    };
+    auto states_of = [&](const int32_t (&e)[4], int32_t (&st)[4]) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) av[t] = vb ? dz[16 * t + c] : 0.0f;       // dZ1^T[j = 16t + c][batch]
+        for (int s = 0; s < 4; ++s) st[s] = e[s] >= 0 ? a.ent_state[e[s]] : 0;
+    };
+    auto values_of = [&](const int32_t (&e)[4], const int32_t (&st)[4], float (&av)[4][4], float (&xv)[4][KU]) {
 #pragma unroll
-            for (int u = 0; u < KU; ++u) { const int i = 16 * u + c; xv[u] = (vb && i < W) ? xrow[i] : 0.0f; }
+        for (int s = 0; s < 4; ++s) {
+            const bool vb = e[s] >= 0;
+            const float* dz = a.DZ + (int64_t)st[s] * HID;
+            const float* xrow = a.ent_obs + (int64_t)(vb ? e[s] : 0) * W;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[s][t] = vb ? dz[16 * t + c] : 0.0f;       // dZ1^T[j = 16t + c][batch]
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { const int i = 16 * u + c; xv[s][u] = (vb && i < W) ? xrow[i] : 0.0f; }
+        }
+    };
+    int64_t tile = (int64_t)part * 4 + wave;
+    int32_t e1[4], e2[4], e3[4], st1[4], st2[4];
+    float av[4][4], xv[4][KU];
+    {
+        int32_t e0[4], st0[4];
+        entries_of(tile, e0); entries_of(tile + stride, e1); entries_of(tile + 2 * stride, e2);
+        states_of(e0, st0); states_of(e1, st1);
+        values_of(e0, st0, av, xv);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        entries_of(tile + 3 * stride, e3);
+        states_of(e2, st2);
+        float an[4][4], xn[4][KU];
+        values_of(e1, st1, an, xn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int u = 0; u < KU; ++u)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xv[u], gW1[t][u], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) gW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], xv[s][u], gW1[t][u], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            e1[s] = e2[s]; e2[s] = e3[s]; st1[s] = st2[s];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[s][t] = an[s][t];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) xv[s][u] = xn[s][u];
         }
     }
     float* out = a.slab + (((int64_t)g * a.split + part) * 4 + wave) * a.slab_stride;
