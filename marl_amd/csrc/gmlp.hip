@@ -395,6 +395,12 @@ extern "C" int em_debug_gfwd_stamps(unsigned long long* out) { return (int)hipMe
 // tiles one ahead, holds the dW1 accumulators and the layer-1 bias gradient and issues dW1 += dZ1^T X as one dense run of
 // register-operand MFMAs per tile.  Three LDS counters per pair order the hand-overs; the sums of every accumulator are taken
 // in the order of the one-wavefront kernel.
+#ifdef EM_STAMP_GBWD   // cycles per phase of one activation wavefront, summed over its tiles (tools/stamp_gbwd.py)
+__device__ unsigned long long gbwd_stamps[2][16];
+#define GBSTAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if ((i) > 0) gb_acc[i] += (unsigned)(n_ - gb_prev); else gb_acc[0] += 1; gb_prev = n_; } while (0)
+#else
+#define GBSTAMP(i) do { } while (0)
+#endif
 template <int KU, int OT, bool ACTOR, bool STAGE = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GArgs a)
 {
@@ -616,10 +622,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    unsigned long long gb_prev = 0; unsigned gb_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)gb_prev; (void)gb_acc;
     for (int64_t tile = (int64_t)part * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;
         const bool valid = row < n_rows;
         const int64_t grow = valid ? grow_cur : 0;
+        GBSTAMP(0);
         const int64_t grow_nn = global_row(tile + 2 * tile_stride);       // needed at the top of the next tile
         const float* xt = xs + cur * XBUF;
         float xb[KU * 4];
@@ -656,8 +664,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                     }
             }
         };
+        GBSTAMP(1);
         forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y, fetch_actions);
 
+        GBSTAMP(2);
         // ---- loss and dL/dy in accumulator layout: dy[ot][r] = d/d out[row c][o = 16 ot + 4q + r] ------------
         if constexpr (ACTOR) {
             float lp = 0.0f;
@@ -720,6 +730,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             }
         }
 
+        GBSTAMP(3);
         if constexpr (SPLIT) {                         // dW3's operands to the gradient wavefront
             wait_flag(F_SDONE3, kt);
 #pragma unroll
@@ -733,6 +744,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             post_flag(F_READY3, kt + 1);
         }
+        GBSTAMP(4);
         // ---- backward through layers 3 and 2 ------------------------------------------------------------------
         f32x4 dz2[4], dz1[4];
 #pragma unroll
@@ -766,6 +778,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             for (int r = 0; r < 4; ++r) dz1[t][r] = h1[t][r] > 0.0f ? dz1[t][r] : 0.0f;
         }
 
+        GBSTAMP(5);
         // ---- weight gradients: reduction over the 16 batch rows of the tile ------------------------------------
         float tr_a[4][4], tr_b[4][4];
         // rowsum: += sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
@@ -811,6 +824,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         }
         }
         if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
+        GBSTAMP(6);
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
         transpose64(dz2, tr_a, &gb2_l);
         transpose64(h1, tr_b, nullptr);
@@ -821,6 +835,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
 #pragma unroll
                 for (int t1 = 0; t1 < 4; ++t1)
                     gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+        GBSTAMP(7);
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
         if constexpr (SPLIT) {                        // dZ1^T to the scratch; the gradient wavefront takes it from there
 #pragma unroll
@@ -861,7 +876,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         if constexpr (STAGE) cur ^= 1;
         grow_cur = grow_next;
         grow_next = grow_nn;
+        GBSTAMP(8);
     }
+#ifdef EM_STAMP_GBWD
+    if (blockIdx.x == 5 && threadIdx.x == 0)
+        for (int i = 0; i < 9; ++i) gbwd_stamps[ACTOR][i] += gb_acc[i];
+#endif
 
     // ---- this wavefront's slab row: [w1 | b1 | w2 | b2 | w3 | b3 | (log_std) | loss, aux, count] ---------------
     float* out = a.slab + (((int64_t)g * a.split + part) * 4 + wave) * a.slab_stride;
@@ -1161,6 +1181,13 @@ void fill_common(GArgs& ga, const em_gmlp* net, const float* x, int64_t ldx, int
 }  // namespace
 
 extern "C" {
+#ifdef EM_STAMP_GBWD
+int em_debug_gbwd_stamps(unsigned long long* out, int reset)
+{
+    if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(gbwd_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gbwd_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 int em_gmlp_forward(const em_gmlp* net, const float* x, int64_t ldx, int64_t n_rows, const int64_t* group_off,
                     const int32_t* perm, int32_t split, float* y, void* stream)
