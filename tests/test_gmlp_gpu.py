@@ -159,6 +159,29 @@ def test_critic_gradients_and_adam():
         _close(v.cpu(), rv, rtol=1e-6)
 
 
+@pytest.mark.parametrize("n_groups,n_per", [(3, 50_001), (1, 1_118_465), (256, 12_866)])
+def test_clip_adam_with_several_workgroups_per_group(n_groups, n_per):
+    """em_group_adam splits a group over several workgroups from 8,192 parameters (the scaled topology's central critic
+    is one group of 1.1 M): every workgroup clips by the same norm, every parameter is updated exactly once."""
+    from marl_amd import gmlp
+    gen = torch.Generator().manual_seed(7)
+    flat = torch.randn((n_groups, n_per), generator=gen) * 0.1
+    grads = torch.randn((n_groups, n_per), generator=gen) * torch.logspace(-3, 0, n_groups).view(-1, 1)   # clipped and unclipped groups
+    p, g = flat.to(DEV), grads.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    rm, rv, rflat = torch.zeros_like(flat), torch.zeros_like(flat), flat.clone()
+    norms = torch.zeros(n_groups, dtype=torch.float32, device=DEV)
+    for step in (1, 2):
+        gmlp.group_adam(p, g, m, v, step, norms_out=norms)
+        rn = io.clip_adam(rflat, grads, rm, rv, step)
+        # the kernel sums the squares in float64; torch's float32 norm of a million elements is 1e-5 off that
+        _close(norms.cpu(), grads.double().norm(dim=1), rtol=1e-6)
+        _close(norms.cpu(), rn, rtol=5e-5)
+        _close(p.cpu(), rflat, rtol=1e-6)
+        _close(m.cpu(), rm, rtol=1e-6)
+        _close(v.cpu(), rv, rtol=1e-6)
+
+
 def test_gae_of_independent_learners():
     from marl_amd import _lib
     import ctypes as C
