@@ -222,7 +222,7 @@ int ems_get_state(ems_handle *h, double *load, double *queue, double *sim_time, 
                   int64_t *counts, void *stream);
 int64_t ems_record_bytes(const ems_handle *h);
 /* Kernel variant: environments per wavefront of the reset/step kernel: 4 (16-lane groups for the pending slots and
- * arrivals; automatic from 32,768 environments) or 1; 0 restores the automatic choice.  Results do not depend on it. */
+ * arrivals; automatic from 16,384 environments) or 1; 0 restores the automatic choice.  Results do not depend on it. */
 int ems_set_envs_per_wave(ems_handle *h, int envs_per_wave);
 
 /* Device buffers of one rollout on the scaled topology (RolloutBuffer, mappo_algorithm.py:93-131; all caller-owned).
