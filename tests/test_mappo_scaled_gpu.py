@@ -146,3 +146,36 @@ def test_scaled_mappo_64x256_smoke():
     assert bool(torch.isfinite(tr.algo.critic.flat).all()) and not torch.equal(before, tr.algo.critic.flat)
     ev = tr.evaluate(num_episodes=96)
     assert all(np.isfinite(v) for v in ev.values())
+
+
+@pytest.mark.parametrize("algorithm", ["mappo", "ippo"])
+def test_deferred_critic_equals_the_per_step_critic(algorithm):
+    """The critic of a recorded rollout evaluated once at the end of the episode (compute_values; the steps are then indexed
+    as one group for the shared actor) gives the values, advantages and parameters of the per-step critic, bit for bit."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 30
+    outs = []
+    for defer in (True, False):
+        tr = IPPOTrainer(cfg, seed=11, device="cuda:0", n_envs=700, algorithm=algorithm, verbose=False)
+        tr.algo.defer_values = defer
+        tr.train_episode(explore=True, record_buffer=True)
+        ro = tr.algo.buffer
+        E = ro.total()
+        rec = {k: ro.t[k][:E].clone() for k in ("ent_obs", "ent_action", "ent_logp", "ent_agent", "ent_env")}
+        key = "value_tb" if algorithm == "mappo" else "ent_value"
+        vals = ro.t[key].clone() if algorithm == "mappo" else ro.t[key][:E].clone()
+        k_tb = ro.t["k_tb"].clone()
+        up = tr.algo.update()
+        outs.append((E, rec, vals, k_tb, up, tr.algo.actor.flat.clone(), tr.algo.critic.flat.clone()))
+    (Ea, ra, va, ka, ua, aa, ca), (Eb, rb, vb, kb, ub, ab, cb) = outs
+    assert Ea == Eb and Ea > 1000 and torch.equal(ka, kb)
+    for k in ra:
+        assert torch.equal(ra[k], rb[k]), k
+    if algorithm == "mappo":
+        has = ka > 0                             # states without an entry keep whatever the storage held
+        assert torch.equal(va[:ka.shape[0]][has], vb[:kb.shape[0]][has])
+    else:
+        assert torch.equal(va, vb)
+    assert ua == ub and torch.equal(aa, ab) and torch.equal(ca, cb)
