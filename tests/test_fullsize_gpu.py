@@ -126,3 +126,54 @@ def test_configs2_full_size_rollout_gae_update():
                 assert torch.equal(got[key], want[key]), f"environment {4 * rank + j}: {key} differs from the 4-environment run"
             assert want["obs"].shape[0] > 500
         small.env.close()
+
+
+@pytest.mark.parametrize("algorithm", ["ippo", "mappo"])
+def test_configs4_full_size_rollout_gae_update(algorithm):
+    """BASELINE.json configs[4] at FULL size (the bench's ippo_scaled / mappo_scaled legs): 64 servers x 256 deciders, 16,384
+    environments x 1000 steps, 36.7 M transitions, deferred critic, two-wavefront backward kernels.  Checked here:
+    bookkeeping (entries == sum of the per-(step, env) pending counts == the step counters, no overflow flag), the
+    advantages and returns of sampled environments against the Python restatement of the GAE recursion on the recorded
+    rewards / values (bit for bit), ret - adv == value, and an update that leaves finite, changed parameters and reports
+    every transition."""
+    from marl_amd.config import SCALED_ENV_CONFIG
+    from marl_amd.ippo import IPPOTrainer
+    from oracle import ippo_oracle as io
+    from oracle import mappo_oracle as mo
+    Bs, Ts = 16384, 1000
+    tr = IPPOTrainer(dict(SCALED_ENV_CONFIG), seed=0, device="cuda:0", n_envs=Bs, algorithm=algorithm, verbose=False)
+    st = tr.train_episode(explore=True, record_buffer=True)
+    ro = tr.algo.buffer
+    t = ro.t
+    E = ro.total()
+    assert st["episode_steps"] == Ts and int(t["err_flag"].item()) == 0
+    assert E == int(t["k_tb"][:Ts].sum(dtype=torch.int64).item()) == int(t["counters"][Ts].item()) and E > 30_000_000
+    before_a, before_c = tr.algo.actor.flat.clone(), tr.algo.critic.flat.clone()
+    sample = (0, Bs // 2 - 1, Bs - 1)
+    k_of = {b: t["k_tb"][:Ts, b].cpu().numpy() for b in sample}          # update() clears the step counts
+    up = tr.algo.update()
+    assert up["transitions"] == E and all(np.isfinite(up[k]) for k in ("actor_loss", "critic_loss", "entropy"))
+    for p, q in ((tr.algo.actor.flat, before_a), (tr.algo.critic.flat, before_c)):
+        assert bool(torch.isfinite(p).all()) and not torch.equal(p, q)
+    for b in sample:
+        k = k_of[b]
+        first = t["first_tb"][:Ts, b].cpu().numpy().astype(np.int64)
+        idx = np.concatenate([np.arange(f, f + kk) for f, kk in zip(first, k)]) if k.sum() else np.zeros(0, np.int64)
+        sel = torch.as_tensor(idx, device=t["ent_adv"].device)
+        adv, ret = t["ent_adv"][sel].cpu().numpy(), t["ent_ret"][sel].cpu().numpy()
+        rew, done = t["reward_tb"][:Ts, b].cpu().numpy(), t["done_tb"][:Ts, b].cpu().numpy()
+        local_first = np.concatenate([[0], np.cumsum(k)[:-1]]).astype(np.int64)
+        assert len(idx) > 1000
+        if algorithm == "ippo":
+            val = t["ent_value"][sel].cpu().numpy()
+            agent = t["ent_agent"][sel].cpu().numpy()
+            want_adv, want_ret = io.gae_agents(rew[:, None], done[:, None], k[:, None], local_first[:, None], agent, val)
+        else:
+            # MAPPO.compute_gae over the environment's flattened list: every entry of a step carries the state's value
+            v_state = t["value_tb"][:Ts, b].cpu().numpy()
+            val = np.repeat(v_state, k)
+            r_flat, d_flat = np.repeat(rew, k), np.repeat(done, k)
+            a64, r64 = mo.gae_flat(list(r_flat), list(val.astype(np.float64)), list(d_flat))
+            want_adv, want_ret = a64.astype(np.float32), r64.astype(np.float32)
+        assert np.array_equal(adv, want_adv), (algorithm, b)
+        assert np.array_equal(ret, want_ret), (algorithm, b)
