@@ -27,10 +27,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# dmabuf IPC: RCCL's peer mappings between ranks need it on this image.  HSA reads the variable when the runtime is
+# initialised (lazily, at the first HIP call), so setting it here - before torch is imported, in EVERY process: a rank
+# started by the driver's own torch.distributed.run as much as one started by launch_ranks() - is early enough.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CLOCK_WARMUP_LAUNCHES = 3000      # ~20 ms of the step kernel on a scratch handle before the warmup steps (see time_env_steps)
+WATCHDOG_EXIT_CODE = 3           # exit status of a run whose secondary leg wedged (see main)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -100,7 +106,13 @@ def cpu_baseline(seconds_target: float = 12.0) -> dict:
         t1 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_timing", "5.0", str(i)], cwd=ROOT, env=env_,
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(P)]
-        res = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+        try:
+            res = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+        finally:                      # no child outlives the leg, whatever happened above
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
         wall = time.perf_counter() - t1
         out["whole_host"] = {"value": sum(r["steps"] * r["n"] / r["seconds"] for r in res), "unit": "agent-steps/s",
                              "processes": P, "sample": f"{P} processes x 5.0 s, one environment each, same restatement",
@@ -250,14 +262,14 @@ def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
                 "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters, "update_s_rank0": upd / iters,
                 "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
                 "parity": "topology is the build's generalisation; arithmetic pinned to the dense torch restatement",
-                "collective": "1 all-reduce of 1,131,336 floats per epoch + 3 doubles per update" if world > 1 else "none"}
+                "collective": "1 all-reduce of 1,131,273 floats per epoch + 3 doubles per update" if world > 1 else "none"}
     return {"metric": "IPPO samples/sec (scaled topology: transitions through rollout + per-agent GAE + 4-epoch PPO update)",
             "value": entries / elapsed, "unit": "transitions/s", "env_steps_per_s": world * n_envs * T * iters / elapsed,
             "agent_steps_per_s": world * n_envs * T * D * iters / elapsed, "n_envs_per_gpu": n_envs, "learners": D,
             "iterations": iters, "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters,
             "update_s_rank0": upd / iters, "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
             "parity": "unpinned vs the reference (RLlib IPPO not vendored); pinned to oracle/ippo_oracle.py",
-            "collective": "1 all-reduce of [256, 21,516] floats per epoch + [256, 3] doubles per update" if world > 1 else "none"}
+            "collective": "1 all-reduce of [256, 21,513] floats per epoch + [256, 3] doubles per update" if world > 1 else "none"}
 
 
 def _cpu_model() -> str:
@@ -524,6 +536,132 @@ def marl_env_leg(device, rank, world, B=65536, steps=400, lanes=0):
                          "bytes_per_env_step": per_step, "bytes_per_launch": per_step * B}}
 
 
+# the three gradient messages of the data-parallel updates (floats per all-reduce): default-topology MAPPO (19,095
+# parameters + 8 loss-sum slots), scaled-topology MAPPO (shared actor + 17,408-wide central critic + loss sums) and IPPO
+# (256 learners x (actor 12,866 + 3 + critic 8,641 + 3)); tests/test_bench_cpu.py holds them to the trainers' buffers
+def _mlp_params(i, o, log_std=False):
+    return i * 64 + 64 + 64 * 64 + 64 + 64 * o + o + (o if log_std else 0)
+
+
+COLLECTIVE_MESSAGES = (
+    ("mappo_grads", (_mlp_params(14, 11, True) + _mlp_params(140, 1) + 8,)),                        # 19,103
+    ("mappo_scaled_grads", (1, _mlp_params(68, 65, True) + 3 + _mlp_params(256 * 68, 1) + 3)),      # 1,131,273
+    ("ippo_grads", (256, _mlp_params(68, 65, True) + 3 + _mlp_params(68, 1) + 3)))                  # [256, 21,513]
+
+
+def collective_probe(device, world, reps=10, warm=3, messages=None):
+    """The `collective` object of an N-rank line: which backend carried the run, how many ranks it saw (a SUM of ones
+    must come back as the world size on every rank) and the duration of each of the three real gradient all-reduces in
+    isolation, from HIP events on the launch stream (torch orders the current stream behind the collective) with the host
+    clock beside it.  Every rank runs it; MAX over ranks is reported.  (A CPU device - the gloo test rig - has no events:
+    host clock only.)"""
+    import torch.distributed as dist
+    device = torch.device(device)
+    gpu = device.type == "cuda"
+    backend = dist.get_backend()
+    drain = gpu and backend != "nccl"   # gloo stages through the host from its own threads (see marl_amd/parallel.py)
+    stream = torch.cuda.current_stream(device) if gpu else None
+
+    def sync():
+        if gpu:
+            torch.cuda.synchronize(device)
+
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    sync()
+    dist.all_reduce(ones)
+    seen = int(round(float(ones.item())))
+    out = {"backend": backend, "is_rccl": backend == "nccl", "world_size": dist.get_world_size(), "ranks_seen_by_sum_of_ones": seen,
+           "placement": "all ranks on one GPU (rehearsal)" if os.environ.get("EDGEMARL_BENCH_DEVICE") is not None else "one GPU per rank",
+           "messages": {}}
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:  # pragma: no cover - informational only
+        out["rccl_version"] = None
+    for name, shape in (COLLECTIVE_MESSAGES if messages is None else messages):
+        buf = torch.ones(shape, dtype=torch.float32, device=device)
+        for _ in range(warm):
+            if drain:
+                stream.synchronize()
+            dist.all_reduce(buf)
+            buf.fill_(1.0)
+        sync()
+        dist.barrier()
+        sync()
+        if gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if drain:
+                stream.synchronize()
+            dist.all_reduce(buf)
+        if gpu:
+            e1.record(stream)
+        sync()
+        host = time.perf_counter() - t0
+        ev = e0.elapsed_time(e1) * 1e3 / reps if gpu else float("nan")
+        tt = torch.tensor([ev if gpu else 0.0, host * 1e6 / reps], dtype=torch.float64, device=device)
+        if drain:
+            stream.synchronize()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        nbytes = buf.numel() * 4
+        ev_us, host_us = (float(tt[0].item()) if gpu else None), float(tt[1].item())
+        # bus bandwidth of an all-reduce in RCCL's own convention: 2 (N - 1) / N x bytes / time
+        out["messages"][name] = {"floats": buf.numel(), "bytes": nbytes, "event_us": ev_us, "host_us": host_us,
+                                 "bus_GBs": 2.0 * (world - 1) / world * nbytes / max(ev_us if gpu else host_us, 1e-3) / 1e3}
+        del buf
+    return out
+
+
+class LineGuard:
+    """The JSON line and its watchdog.  The headline exists before the secondary legs run; they only add objects to it.  A
+    leg that never returns (a wedged collective or GPU sync cannot be caught as an exception) is a FAILED run: after
+    `limit` seconds the watchdog prints what there is, for the record, and ends the process with WATCHDOG_EXIT_CODE.
+    `line` is shared between the main thread and the watchdog thread: every mutation and the serialisation go through one
+    lock, the watchdog serialises a snapshot, and its body ends in os._exit whatever happens on the way."""
+
+    def __init__(self, line: dict, rank: int, limit_s: float):
+        self.line, self.rank, self.limit = line, int(rank), float(limit_s)
+        self.lock, self.printed = threading.Lock(), threading.Lock()
+        self.current_leg = ["start"]
+        self.timer = threading.Timer(self.limit, self._watchdog)
+        self.timer.daemon = True
+
+    def start(self):
+        self.timer.start()
+
+    def put(self, key, value):
+        with self.lock:
+            self.line[key] = value
+
+    def emit(self, note=None):
+        if not self.printed.acquire(blocking=False):
+            return
+        with self.lock:
+            if note:
+                self.line["legs_cut_short"] = note
+            text = json.dumps(dict(self.line))
+        if self.rank == 0:
+            print(text, flush=True)
+
+    def _watchdog(self):
+        try:
+            self.emit(f"watchdog after {self.limit:.0f} s: leg '{self.current_leg[0]}' did not return; objects present so far "
+                      f"are complete; exit status {WATCHDOG_EXIT_CODE}")
+            print(f"[bench] rank {self.rank}: watchdog after {self.limit:.0f} s in leg '{self.current_leg[0]}'",
+                  file=sys.stderr, flush=True)
+            time.sleep(2.0 if self.rank == 0 else 6.0)      # rank 0's line first, then everyone leaves
+        finally:
+            os._exit(WATCHDOG_EXIT_CODE)
+
+    def finish(self):
+        self.current_leg[0] = "done"
+        self.timer.cancel()
+        if self.timer.ident is not None:  # started: a cancelled Timer thread ends at once, nothing outlives main()
+            self.timer.join(timeout=1.0)
+        self.emit()
+
+
 def guarded(name, fn, *a, **k):
     """Secondary legs (everything beside the headline measurement) must not cost the headline line: a Python-level
     failure is reported in the leg's object and on stderr.  The same code runs on every rank, so a deterministic failure
@@ -661,55 +799,47 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src, "bytes_per_launch": bytes_launch, "avg_launch_us": launch_s * 1e6},
     }
-    printed = threading.Lock()
+    guard = LineGuard(line, rank, float(os.environ.get("EDGEMARL_BENCH_WATCHDOG_S", "900")))
+    put, emit, current_leg = guard.put, guard.emit, guard.current_leg
+    guard.start()
 
-    def emit(note=None):
-        if not printed.acquire(blocking=False):
-            return
-        if note:
-            line["legs_cut_short"] = note
-        if rank == 0:
-            print(json.dumps(line), flush=True)
+    def leg(key, fn, *a, **k):
+        current_leg[0] = key
+        put(key, guarded(key, fn, *a, **k))
 
-    def watchdog():
-        emit(f"watchdog after {limit:.0f} s: a secondary leg did not return; objects present so far are complete")
-        time.sleep(2.0 if rank == 0 else 6.0)      # rank 0's line first, then everyone leaves
-        os._exit(0)
-
-    limit = float(os.environ.get("EDGEMARL_BENCH_WATCHDOG_S", "900"))
-    timer = threading.Timer(limit, watchdog)
-    timer.daemon = True
-    timer.start()
-
+    if world > 1:
+        # proof that the run's collectives went through the backend named, with N ranks, and what the three real
+        # gradient messages cost on it
+        leg("collective", collective_probe, device, world)
     if not args.no_scale_point and B != 65536:
         # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)
         k = max(200, args.steps // 4)
+        current_leg[0] = "scale_point"
         res = guarded("scale_point", time_env_steps, device, rank, world, 65536, k, max(20, args.warmup // 4))
         if isinstance(res, tuple):
             se, sd, sv = res[0], res[1], res[5]
             s_bytes = algorithmic_bytes_per_env_step(n, record_bytes) * 65536
             s_ach = s_bytes / (sd * 1e-3 / k) / 1e9
             s_traffic, s_src = traffic_for(65536)
-            line["scale_point"] = {"n_envs_per_gpu": 65536, "steps": k, "value": world * 65536 * n * k / se,
-                                   "unit": "agent-steps/s", "avg_launch_us": sd * 1e3 / k,
-                                   "lanes_per_env": sv["lanes_per_env"], "kernel": sv["kernel"],
-                                   "roofline": {"bound": "hbm", "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": s_ach / HBM_PEAK_GBS, "traffic": s_traffic,
-                                                "traffic_source": s_src, "bytes_per_launch": s_bytes}}
+            put("scale_point", {"n_envs_per_gpu": 65536, "steps": k, "value": world * 65536 * n * k / se,
+                                "unit": "agent-steps/s", "avg_launch_us": sd * 1e3 / k,
+                                "lanes_per_env": sv["lanes_per_env"], "kernel": sv["kernel"],
+                                "roofline": {"bound": "hbm", "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": s_ach / HBM_PEAK_GBS, "traffic": s_traffic,
+                                             "traffic_source": s_src, "bytes_per_launch": s_bytes}})
         else:
-            line["scale_point"] = res
+            put("scale_point", res)
     if not args.no_scale_point:
-        line["fused_steps"] = guarded("fused_steps", fused_leg, device, rank, world, B)
-        line["scaled_topology"] = guarded("scaled_topology", scaled_leg, device, rank, world)
-        line["pymarl_env"] = guarded("pymarl_env", marl_env_leg, device, rank, world)
+        leg("fused_steps", fused_leg, device, rank, world, B)
+        leg("scaled_topology", scaled_leg, device, rank, world)
+        leg("pymarl_env", marl_env_leg, device, rank, world)
     if not args.no_mappo:
-        line["mappo"] = guarded("mappo", mappo_leg, device, rank, world, args.mappo_envs)
-        line["ippo_scaled"] = guarded("ippo_scaled", ippo_leg, device, rank, world)
-        line["mappo_scaled"] = guarded("mappo_scaled", ippo_leg, device, rank, world, algorithm="mappo")
+        leg("mappo", mappo_leg, device, rank, world, args.mappo_envs)
+        leg("ippo_scaled", ippo_leg, device, rank, world)
+        leg("mappo_scaled", ippo_leg, device, rank, world, algorithm="mappo")
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline)
-    timer.cancel()
-    emit()
+        leg("cpu_baseline", cpu_baseline)
+    guard.finish()
     if world > 1:
         dist.destroy_process_group()
 

@@ -392,7 +392,9 @@ int em_gae(const em_rollout *ro, double gamma, double lam, double *partials, int
  * hipMalloc/hipFree, no allocating library routine); its first call on a device resolves the array's device address
  * (hipGetSymbolAddress), so make one call per device before a graph capture begins.  n_envs above
  * EM_GAE_STATIC_MAX_ENVS is rejected with EM_ERR_INVALID.  Every call on a GPU shares that GPU's array: calls that
- * overlap on one GPU (two streams, two host threads) race; calls on one stream are ordered and need no clearing. */
+ * overlap on one GPU (two streams, two host threads) race; calls on one stream are ordered and need no clearing.
+ * The array used is the CURRENT device's: `stream` (and the rollout buffers) must belong to the current device; a stream of
+ * another device is rejected with EM_ERR_INVALID. */
 #define EM_GAE_STATIC_MAX_ENVS (1 << 20)
 int em_gae_static(const em_rollout *ro, double gamma, double lam, double *moments3, void *stream);
 

@@ -119,7 +119,8 @@ def mean_arrivals_bound(config: dict, margin: float = 1.25) -> float:
 def latency_log_capacity(config: dict, n_envs: int, per_step_cap: int) -> int:
     """Per-environment capacity of the latency log behind the exact p99 metric (MRRL.PY:476-479 keeps EVERY latency of
     the episode).  Small batches get the hard worst case (``per_step_cap`` tasks every step); large ones 1.5x the bound on
-    the mean number of tasks of an episode, rounded up to a power of two (the metrics kernel sorts in LDS): 2,048 doubles =
+    the mean number of tasks of an episode, rounded up to a power of two (a convention kept from the LDS sort of round 1; the
+    selection kernel that replaced it takes any length): 2,048 doubles =
     16 KB per environment at the default config, where an episode dispatches ~870 tasks with a standard deviation of ~30.
     An environment that overflows its log reports NaN for p99 (and only for p99); callers count such environments."""
     T = int(config.get("episode_length", 1000))

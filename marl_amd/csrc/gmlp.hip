@@ -992,6 +992,7 @@ __global__ __launch_bounds__(256) void group_adam_kernel(const GroupAdam a, int 
     float coef = a.max_norm / (total_norm + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (threadIdx.x == 0 && part == 0 && norms_out) norms_out[g] = total_norm;
+    if (!(total_norm <= 3.0e38f)) return;        // as adam_kernel: a non-finite gradient never reaches the parameters
     const int64_t per = (a.n_per_group + parts - 1) / parts;
     const int64_t i0 = (int64_t)part * per, i1 = i0 + per < a.n_per_group ? i0 + per : a.n_per_group;
     for (int64_t k = i0 + threadIdx.x; k < i1; k += 256) {

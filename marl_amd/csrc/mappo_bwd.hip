@@ -940,6 +940,10 @@ __global__ __launch_bounds__(1024) void adam_kernel(const AdamGroup g0, const Ad
     float coef = g.max_norm / (total_norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
     coef = coef > 1.0f ? 1.0f : coef;
     if (threadIdx.x == 0 && norms_out) norms_out[blockIdx.x] = total_norm;
+    // A gradient that is not finite (a lost hand-over of the two-wavefront backward kernel poisons its slab with NaN; a
+    // diverged run does the same) must not reach the parameters: the step is skipped for this network, the norm that the
+    // host reads back says why, and MAPPO.update() raises.  (torch would write NaN into every parameter here.)
+    if (!(total_norm <= 3.0e38f)) return;
     const float step_size = g.step_size;
     for (int64_t i = threadIdx.x; i < g.n; i += 1024) {
         const float gr = g.grad[i] * coef;
@@ -1037,6 +1041,12 @@ int em_gae_static(const em_rollout* ro, double gamma, double lam, double* moment
     int dev = -1;
     EM_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= GAE_MAX_DEVICES) return em::fail(EM_ERR_INVALID, "em_gae_static: device index %d out of range", dev);
+    // the scratch pointer belongs to the CURRENT device; a stream of another GPU would run the kernels there with this
+    // GPU's address.  The precondition "current device == the stream's device" is checked, not assumed.
+    hipDevice_t sdev = dev;
+    if (stream && hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && (int)sdev != dev)
+        return em::fail(EM_ERR_INVALID, "em_gae_static: the stream belongs to device %d but device %d is current; make the "
+                        "stream's device current (hipSetDevice) before the call", (int)sdev, dev);
     double* part = g_gae_scratch_ptr[dev].load(std::memory_order_acquire);
     if (!part) {
         // once per device, with that device current: every GPU holds its own copy of the array at its own address

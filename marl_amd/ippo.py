@@ -24,6 +24,7 @@ from . import _lib, gmlp
 from .config import SCALED_ENV_CONFIG, mean_arrivals_bound, summarise_episode_metrics
 from .env import METRIC_KEYS
 from .env_scaled import PENDING_CAP, ScaledEdgeSimGym
+from .mappo import _require_finite
 from .parallel import GradSync
 
 _STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tps", "load_balance_jain")
@@ -63,6 +64,7 @@ class ScaledRolloutStorage:
     def clear(self):
         self.t["counters"].zero_()
         self.t["k_tb"].zero_()
+        self.t["err_flag"].zero_()        # sticky per batch, not per storage
         self.steps_recorded = 0
         self.values_through = 0           # recorded steps whose entries have a value (deferred critic, IPPO.compute_values)
         self.group_cache = None           # ((entries, steps), offsets, permutation) of IPPO._grouping
@@ -249,6 +251,7 @@ class IPPO:
             acc[3:] += self.l_critic.sum(0).double()
         ro.clear()
         s = acc.cpu()
+        _require_finite(s)
         k = float(self.num_sgd_iter) * n_global
         self.last_update = {"actor_loss": float(-s[0] / k), "critic_loss": float(0.5 * s[3] / k), "entropy": float(s[1] / k),
                             "transitions": n_global}

@@ -286,6 +286,7 @@ class RolloutStorage:
     def clear(self):
         self.t["counters"].zero_()
         self.t["k_tb"].zero_()
+        self.t["err_flag"].zero_()        # the overflow flag is sticky per batch, not per storage: the next batch starts clean
         self.steps_recorded = 0
         self.staged.clear()
 
@@ -540,6 +541,12 @@ class MAPPO:
 
     def update(self):
         ro = self.buffer
+        if len(ro.staged) and ro.steps_recorded:
+            # two sources at once: the list interface (buffer.add) and a device-recorded episode.  The reference has ONE
+            # list; merging a host list into env-major device records has no defined order, and dropping either silently
+            # would lose transitions
+            raise RuntimeError(f"{len(ro.staged)} transitions were added through buffer.add() while {ro.steps_recorded} recorded "
+                               "steps of a batched episode are pending: call update() after each kind, not after both")
         if len(ro.staged) and ro.steps_recorded == 0:
             # transitions added through the reference's list interface (buffer.add, mappo_trainer.py:160-175)
             listed = RolloutStorage.from_lists(ro.staged.get(), self.n_agents, self.device)
@@ -606,6 +613,7 @@ class MAPPO:
         ro.clear()
         self._values_through = 0
         sums = acc.cpu()
+        _require_finite(sums, self.grad_norms)
         k = float(self.num_sgd_iter) * n_global
         self.last_update = {"actor_loss": float(-sums[0] / k), "critic_loss": float(0.5 * sums[4] / k),
                             "entropy": float(sums[1] / k), "transitions": n_global}
@@ -682,6 +690,20 @@ class MAPPO:
         self.actor_optimizer.load_state_dict(ck["actor_optimizer"])
         self.critic_optimizer.load_state_dict(ck["critic_optimizer"])
         self.value_normalizer.load_state_dict({k: v.to(self.device) for k, v in ck["value_normalizer"].items()})
+
+
+def _require_finite(loss_sums, grad_norms=None):
+    """The update's only silent failure mode made loud: a non-finite loss sum or gradient norm.  The Adam kernels skip a
+    step whose gradient norm is not finite (parameters stay as they were), and this raises.  Causes: a diverged run, or a
+    lost hand-over between the two wavefronts of the split backward kernels (their bounded wait poisons the slab with NaN;
+    EM_BWD_SPLIT=0 selects the one-wavefront kernels, bitwise the same results)."""
+    bad = not bool(torch.isfinite(loss_sums).all())
+    if grad_norms is not None:
+        bad = bad or not bool(torch.isfinite(grad_norms).all().item())
+    if bad:
+        raise RuntimeError("update(): non-finite loss sums or gradient norm; the optimiser step of the affected network was "
+                           "skipped (parameters unchanged).  If the inputs are finite, set EM_BWD_SPLIT=0 (one-wavefront "
+                           "backward kernels) and report the case")
 
 
 def _cpu(obj):

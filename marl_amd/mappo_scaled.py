@@ -15,6 +15,7 @@ import torch
 
 from . import _lib, gmlp
 from .ippo import IPPO, ScaledRolloutStorage, _stream
+from .mappo import _require_finite
 
 HID = 64
 
@@ -198,6 +199,7 @@ class ScaledMAPPO(IPPO):
             acc[3:] += self.l_critic[0].double()
         ro.clear()
         s = acc.cpu()
+        _require_finite(s)
         k = float(self.num_sgd_iter) * n_global
         self.last_update = {"actor_loss": float(-s[0] / k), "critic_loss": float(0.5 * s[3] / k), "entropy": float(s[1] / k),
                             "transitions": n_global}

@@ -14,6 +14,7 @@ import torch
 from .config import ENV_CONFIG, mean_arrivals_bound, summarise_episode_metrics
 from .env import METRIC_KEYS, BatchedEdgeSimGym
 from .mappo import MAPPO, RolloutStorage
+from .parallel import GradSync
 
 _STAT_KEYS = ("avg_latency_ms", "p99_latency_ms", "avg_energy_J", "throughput_tps", "load_balance_jain")
 
@@ -38,10 +39,15 @@ class MAPPOTrainer:
         self.n_agents = int(cfg["n_nodes"])
         # the reference probes up to ten reseeded resets for a non-empty observation (mappo_trainer.py:53-58),
         # which leaves the environment stream keyed by seed + attempt
+        # Data parallel: the probe stops on the OR over ALL ranks of "some environment has an observation" - the condition
+        # the one-process run on the union of the shards evaluates - so every rank leaves the loop at the same
+        # seed + attempt (a rank-local test could stop two small shards at different attempts, i.e. on different streams).
+        probe = GradSync(process_group)
         for attempt in range(10):
             _, active = self.env.reset(seed=self.seed + attempt)
-            if bool((active != 0).any()):
+            if probe.sum_counts([int(bool((active != 0).any()))], self.device)[0] > 0:
                 break
+        self.reset_attempts = attempt + 1
         self.obs_dim = 5 + (self.n_agents - 1)
         self.action_dim = self.n_agents + 1
         self.state_dim = self.obs_dim * self.n_agents

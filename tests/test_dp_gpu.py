@@ -187,3 +187,102 @@ def test_ippo_two_ranks_match_one_process(tmp_path, algorithm):
     d = np.abs(p0 - single)
     # Adam turns a last-bit difference of a ~1e-8 gradient into a fraction of lr: bound the outliers (tests/test_ippo_gpu.py)
     assert (d > 2e-6 + 2e-4 * np.abs(single)).mean() < 1e-4 and d.max() <= 3e-4 * 4 * UPDATES
+
+
+# ---- the constructor's reset probe stops at the same seed + attempt on every rank (mappo_trainer.py:53-58) ---------------
+def _sparse_cfg():
+    cfg = _cfg()
+    cfg.update(task_arrival_rate=2, task_arrival_rate_range=(2, 2))      # reset: Poisson(0.2) arrivals, empty 82 % of the time
+    return cfg
+
+
+def _probe_worker(rank, world, port, out_dir, seed):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_sparse_cfg(), seed=seed, device="cuda:0", n_envs=1, rank=rank, world_size=world, verbose=False)
+    np.save(os.path.join(out_dir, f"probe_{rank}.npy"), np.array([tr.reset_attempts]))
+    np.save(os.path.join(out_dir, f"probe_obs_{rank}.npy"), tr.env.obs.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_reset_probe_is_rank_consistent(tmp_path):
+    """One environment per rank, arrivals rare: find a seed where, at the attempt the one-process run on the union stops at,
+    rank 0's environment is EMPTY and rank 1's is not.  A rank-local test would send rank 0 on to the next seed; the
+    all-reduced test stops both where the union stops, with the union's observations."""
+    from marl_amd.env import BatchedEdgeSimGym
+    from marl_amd.trainer import MAPPOTrainer
+    env = BatchedEdgeSimGym(_sparse_cfg(), n_envs=2, device="cuda:0", seed=0)
+    seed = None
+    for s in range(200):
+        _, active = env.reset(seed=s)
+        a = (active != 0).cpu().numpy()
+        if not a[0] and a[1]:
+            seed = s
+            break
+    env.close()
+    assert seed is not None
+    union = MAPPOTrainer(_sparse_cfg(), seed=seed, device="cuda:0", n_envs=2, verbose=False)
+    assert union.reset_attempts == 1
+    mp.spawn(_probe_worker, args=(2, _free_port(), str(tmp_path), seed), nprocs=2, join=True)
+    a0, a1 = (int(np.load(tmp_path / f"probe_{r}.npy")[0]) for r in range(2))
+    assert a0 == a1 == union.reset_attempts
+    want = union.env.obs.cpu().numpy()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"probe_obs_{r}.npy")[0], want[r])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+# ---- an overflowed batch is followed by a fitting one (the error flag is per batch, not per storage) -------------------------
+def test_update_recovers_after_an_overflowed_batch():
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=6, verbose=False, capacity_entries=200)
+    tr.train_episode(explore=True, record_buffer=True)           # ~6 x 60 x 0.87 = 310 entries: does not fit 200
+    with pytest.raises(RuntimeError, match="capacity 200 entries"):
+        tr.mappo.update()
+    before = tr.mappo.flat_params.clone()
+    # a batch that fits (low load) on a storage whose flag an earlier overflowed batch left set
+    low = MAPPOTrainer({**_cfg(), "task_arrival_rate": 2, "task_arrival_rate_range": (2, 2)}, seed=3, device="cuda:0", n_envs=6,
+                       verbose=False, capacity_entries=200)
+    low.mappo.buffer.t["err_flag"].fill_(8)                      # what an earlier overflowed batch left behind
+    low.train_episode(explore=True, record_buffer=True)
+    out = low.mappo.update()
+    assert np.isfinite(out["critic_loss"]) and low.mappo.last_update["transitions"] > 0
+    # and on the trainer that really overflowed: the next update() neither raises "capacity exceeded" on an empty storage nor
+    # changes anything
+    assert tr.mappo.update() == {}
+    assert torch.equal(before, tr.mappo.flat_params)
+
+
+def test_update_refuses_list_transitions_beside_a_recorded_episode():
+    from marl_amd.trainer import MAPPOTrainer
+    tr = MAPPOTrainer(_cfg(), seed=3, device="cuda:0", n_envs=2, verbose=False)
+    tr.train_episode(explore=True, record_buffer=True)
+    z = np.zeros
+    tr.mappo.buffer.add(obs=z(14, np.float32), state=z(140, np.float32), action=z(11, np.float32), reward=0.0, done=False,
+                        log_prob=0.0, value=0.0)
+    with pytest.raises(RuntimeError, match="buffer.add"):
+        tr.mappo.update()
+
+
+def test_bench_collective_messages_are_the_trainers_buffers():
+    import bench
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.trainer import MAPPOTrainer
+    m = dict(bench.COLLECTIVE_MESSAGES)
+    tr = MAPPOTrainer(_cfg(), seed=0, device="cuda:0", n_envs=2, verbose=False)
+    assert tuple(tr.mappo.flat_grads.shape) == m["mappo_grads"]
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG, episode_length=4)
+    for alg, key in (("ippo", "ippo_grads"), ("mappo", "mappo_scaled_grads")):
+        t2 = IPPOTrainer(cfg, seed=0, device="cuda:0", n_envs=2, verbose=False, algorithm=alg)
+        assert tuple(t2.algo.grads.shape) == m[key]
+        t2.env.close()
