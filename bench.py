@@ -805,7 +805,10 @@ def main():
 
     def leg(key, fn, *a, **k):
         current_leg[0] = key
+        t_leg = time.perf_counter()
         put(key, guarded(key, fn, *a, **k))
+        if rank == 0:      # progress on stderr: the line itself is printed once, at the end
+            print(f"[bench] {key}: {time.perf_counter() - t_leg:.1f} s", file=sys.stderr, flush=True)
 
     if world > 1:
         # proof that the run's collectives went through the backend named, with N ranks, and what the three real
@@ -815,6 +818,8 @@ def main():
         # north_star's ">= 65k concurrent envs": same kernel, same timing protocol, 16x the batch (not part of `value`)
         k = max(200, args.steps // 4)
         current_leg[0] = "scale_point"
+        if rank == 0:
+            print(f"[bench] headline measured ({agent_steps / elapsed:.3e} agent-steps/s); secondary legs follow", file=sys.stderr, flush=True)
         res = guarded("scale_point", time_env_steps, device, rank, world, 65536, k, max(20, args.warmup // 4))
         if isinstance(res, tuple):
             se, sd, sv = res[0], res[1], res[5]
