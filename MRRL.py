@@ -5,6 +5,7 @@ from marl_amd.baselines import run_greedy_baseline  # noqa: F401
 from marl_amd.config import ENV_CONFIG  # noqa: F401
 from marl_amd.dict_env import EdgeSimGym  # noqa: F401
 from marl_amd.env import BatchedEdgeSimGym  # noqa: F401
+from marl_amd.experiment import run_experiment  # noqa: F401
 from marl_amd.trainer import run_mappo_experiment  # noqa: F401
 
 MAPPO_AVAILABLE = True
