@@ -202,6 +202,9 @@ def main():
 # ------------------------------------------------------------------------------------------------
 # MAPPO goldens: one reference episode of MAPPOTrainer(seed=0) + the first update()
 # ------------------------------------------------------------------------------------------------
+HYPER = {"lr_act": 1e-4, "lr_cri": 1e-3, "clip": 0.15, "entropy": 0.005, "num_sgd": 6, "batch": 256}
+
+
 def run_mappo_scenario(name="mappo_seed0_T200", seed=0, T=200):
     import copy
 
@@ -266,6 +269,16 @@ def run_mappo_scenario(name="mappo_seed0_T200", seed=0, T=200):
         loss1 = m1.update()
         params1 = {f"actor.{k}": v.detach().numpy().copy() for k, v in m1.actor.state_dict().items()}
         params1.update({f"critic.{k}": v.detach().numpy().copy() for k, v in m1.critic.state_dict().items()})
+        # run_mappo_batch.py:255-261: the sweep pokes these attributes after construction; one update with every one of
+        # them off its default (distinct learning rates per network, 6 epochs) pins that they take effect
+        mh = copy.deepcopy(tr.mappo)
+        mh.actor_optimizer.param_groups[0]["lr"] = HYPER["lr_act"]
+        mh.critic_optimizer.param_groups[0]["lr"] = HYPER["lr_cri"]
+        mh.clip_param, mh.entropy_coeff, mh.num_sgd_iter = HYPER["clip"], HYPER["entropy"], HYPER["num_sgd"]
+        mh.mini_batch_size = HYPER["batch"]
+        lossh = mh.update()
+        paramsh = {f"actor.{k}": v.detach().numpy().copy() for k, v in mh.actor.state_dict().items()}
+        paramsh.update({f"critic.{k}": v.detach().numpy().copy() for k, v in mh.critic.state_dict().items()})
         loss4 = tr.mappo.update()
         params4 = {f"actor.{k}": v.detach().numpy().copy() for k, v in tr.mappo.actor.state_dict().items()}
         params4.update({f"critic.{k}": v.detach().numpy().copy() for k, v in tr.mappo.critic.state_dict().items()})
@@ -312,6 +325,9 @@ def run_mappo_scenario(name="mappo_seed0_T200", seed=0, T=200):
         noise=eps, gae_adv=np.array(adv, np.float64), gae_ret=np.array(ret, np.float64),
         loss1=np.array([loss1["actor_loss"], loss1["critic_loss"], loss1["entropy"]]),
         loss4=np.array([loss4["actor_loss"], loss4["critic_loss"], loss4["entropy"]]),
+        lossh=np.array([lossh["actor_loss"], lossh["critic_loss"], lossh["entropy"]]),
+        hyper=np.array([HYPER[k] for k in ("lr_act", "lr_cri", "clip", "entropy", "num_sgd")], np.float64),
+        **{f"ph.{k}": v for k, v in paramsh.items()},
         **{f"init.{k}": v for k, v in init_params.items()},
         **{f"p1.{k}": v for k, v in params1.items()},
         **{f"p4.{k}": v for k, v in params4.items()},
@@ -324,5 +340,7 @@ if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--mappo" not in sys.argv:
         main()
-    if not names:
+    if "--mappo-full" in sys.argv:       # configs[0] at its real length (reward -1787.630, 883 transitions)
+        run_mappo_scenario("mappo_seed0_T1000", 0, 1000)
+    elif not names:
         run_mappo_scenario()

@@ -46,14 +46,30 @@ def test_seeded_init_equals_reference():
         assert np.array_equal(v, g["init"][k]), k
 
 
-def test_rollout_gae_update_parity():
-    g = load()
+def _apply_overrides(m, g):
+    """The attribute overrides of run_mappo_batch.py:255-261, with the values the golden update was recorded with."""
+    lr_a, lr_c, clip, ent, n_iter = g["hyper"].tolist()
+    m.actor_optimizer.param_groups[0]["lr"] = lr_a
+    m.critic_optimizer.param_groups[0]["lr"] = lr_c
+    m.clip_param, m.entropy_coeff, m.num_sgd_iter = clip, ent, int(n_iter)
+    m.mini_batch_size = 256          # inert in the reference too
+
+
+@pytest.mark.parametrize("name", ["mappo_seed0_T200", "mappo_seed0_T1000"])
+def test_rollout_gae_update_parity(name):
+    """T200: a short episode; T1000: configs[0] at its real length (reward -1787.630, 883 transitions) with a
+    third update whose hyper-parameters are all overridden (distinct learning rates, clip 0.15, entropy 0.005, 6 epochs)."""
+    g = load(name)
     obs_flat, states_flat, step_of = flatten_buffer(g)
     L = len(step_of)
-    for n_iter, pkey, lkey in ((1, "p1", "loss1"), (4, "p4", "loss4")):
+    cases = [(1, "p1", "loss1"), (4, "p4", "loss4")] + ([(None, "ph", "lossh")] if g["ph"] else [])
+    for n_iter, pkey, lkey in cases:
         tr = _trainer(g)
         m = tr.mappo
-        m.num_sgd_iter = n_iter
+        if n_iter is None:
+            _apply_overrides(m, g)
+        else:
+            m.num_sgd_iter = n_iter
         stats = _rollout(g, tr)
         ro = m.buffer
         E, S = ro.totals()
