@@ -179,6 +179,30 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    # per-kernel share of a rollout step, outside the timed region: one more episode with three events per step
+    tr.profile_events = []
+    t_ep = time.perf_counter()
+    tr.train_episode(explore=True, record_buffer=True)
+    torch.cuda.synchronize(device)
+    t_ep = time.perf_counter() - t_ep
+    evs, tr.profile_events = tr.profile_events, None
+    pol_us = sum(a.elapsed_time(b) for a, b, _ in evs) * 1e3 / len(evs)
+    env_us = sum(b.elapsed_time(c) for _, b, c in evs) * 1e3 / len(evs)
+    e_ep, s_ep = tr.mappo.buffer.totals()
+    tr.mappo.buffer.clear()
+    env_bytes = algorithmic_bytes_per_env_step(tr.n_agents, tr.env.record_bytes) * n_envs
+    rollout_roofline = {
+        "per_step_gpu_us": {"env_step": env_us, "index_and_actor": pol_us, "sum": env_us + pol_us},
+        "env_step": {"bound": "hbm", "achieved": env_bytes / (env_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": env_bytes / (env_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": env_bytes},
+        "index_and_actor": {"bound": "mfma", "achieved": 11392.0 * e_ep / T / (pol_us * 1e-6) / 1e12, "peak": 157.3,
+                            "unit": "TFLOP/s", "frac": 11392.0 * e_ep / T / (pol_us * 1e-6) / 1e12 / 157.3,
+                            "rows_per_launch": e_ep / T,
+                            "note": "actor forward FLOPs (11,392 per acting agent) over the whole launch, which also numbers and "
+                                    "copies the step's entries and samples/formats the actions: latency bound, not MFMA bound"},
+        "episode_wall_s_with_events": t_ep,
+        "note": "HIP events on the launch stream around each launch of one extra episode (3 events per step); the two "
+                "launches of a step are dependent and run one after the other"}
     stat = torch.tensor([elapsed, float(entries)], device=device, dtype=torch.float64)
     if world > 1:
         tmax = stat.clone()
@@ -203,6 +227,7 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
                                         "32,384, critic 60,800 per row and epoch) over the update's whole wall time (GAE, "
                                         "reductions, Adam included); mfma_issue_frac: time the issued MFMA instructions need "
                                         "at 2.4 GHz over the same wall time; survey_convention_frac: 3 x forward FLOPs"},
+            "rollout_roofline": rollout_roofline,
             "rollout": "two launches per step (env step; entry numbering + copy + actor in one kernel), states by reference, "
                        "acting-agent totals from the step kernel, one critic launch per episode (inside rollout_s)",
             "update": "4 epochs x (actor + critic fused forward/loss/backward); the critic kernel runs two wavefronts per SIMD "
@@ -225,11 +250,16 @@ def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
         tr.train_episode(explore=True, record_buffer=True)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
+        e_local = tr.algo.buffer.total() if tr.algo.buffer.steps_recorded else 0
         out = tr.algo.update()
         torch.cuda.synchronize(device)
+        work["entries"] += e_local
+        work["epochs"] = float(tr.algo.num_sgd_iter)
         return out.get("transitions", 0), t1 - t0, time.perf_counter() - t1
 
+    work = {"entries": 0, "epochs": 4.0}
     iteration()
+    work["entries"] = 0
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -255,15 +285,27 @@ def ippo_leg(device, rank, world, n_envs=16384, iters=2, algorithm="ippo"):
     torch.cuda.empty_cache()
     if rank != 0:
         return None
+    # useful FLOPs per row and epoch (forward + every weight gradient + dX of layers 2 and 3), rank 0's rows over its update
+    # wall time (GAE, grouping, reductions, Adam and the collectives included) against the dense f32 matrix-core peak.
+    # grouped actor 68-64-64-65: 2 x 25,216 + 16,512; local critic 68-64-64-1: 2 x 17,024 + 8,320; central critic: sparse
+    # first layer 2 x 8,704 per entry + head (layers 2-3) 24,960 per (step, env) state - counted per entry here, an upper
+    # bound of 1 state per entry
+    per_row = (66944.0 + 42368.0) if algorithm != "mappo" else (66944.0 + 17408.0 + 24960.0)
+    useful = work["epochs"] * per_row * work["entries"]
+    update_roofline = {"bound": "mfma", "achieved": useful / max(upd, 1e-9) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                       "frac": useful / max(upd, 1e-9) / 1e12 / 157.3, "flop_per_row_epoch": per_row,
+                       "note": "useful FLOPs (forward + weight gradients + dX of layers 2-3) of rank 0's rows over the update's "
+                               "whole wall time; padding of 68 -> 80 inputs and 65 -> 80 outputs is not counted as work"}
     if algorithm == "mappo":
-        return {"metric": "MAPPO samples/sec (scaled topology: shared actor + central 17,408-wide critic, sparse first layer)",
+        return {"update_roofline": update_roofline, "metric": "MAPPO samples/sec (scaled topology: shared actor + central 17,408-wide critic, sparse first layer)",
                 "value": entries / elapsed, "unit": "transitions/s", "env_steps_per_s": world * n_envs * T * iters / elapsed,
                 "agent_steps_per_s": world * n_envs * T * 256 * iters / elapsed, "n_envs_per_gpu": n_envs, "iterations": iters,
                 "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters, "update_s_rank0": upd / iters,
                 "dtype": "f32 (MFMA) / f64 env", "parallelism": f"dp{world}",
                 "parity": "topology is the build's generalisation; arithmetic pinned to the dense torch restatement",
                 "collective": "1 all-reduce of 1,131,273 floats per epoch + 3 doubles per update" if world > 1 else "none"}
-    return {"metric": "IPPO samples/sec (scaled topology: transitions through rollout + per-agent GAE + 4-epoch PPO update)",
+    return {"update_roofline": update_roofline,
+            "metric": "IPPO samples/sec (scaled topology: transitions through rollout + per-agent GAE + 4-epoch PPO update)",
             "value": entries / elapsed, "unit": "transitions/s", "env_steps_per_s": world * n_envs * T * iters / elapsed,
             "agent_steps_per_s": world * n_envs * T * D * iters / elapsed, "n_envs_per_gpu": n_envs, "learners": D,
             "iterations": iters, "s_per_iteration": elapsed / iters, "rollout_s_rank0": roll / iters,

@@ -65,6 +65,9 @@ class MAPPOTrainer:
         self._scratch_storage = None
         self.policy_episode = 0
         self.overlap_value = True      # value forward on a side stream during recorded rollouts (identical results)
+        # measurement hook (bench.py): a list here makes train_episode record three events per step on the launch stream -
+        # before the index/actor launch, between it and the environment step, after the step
+        self.profile_events = None
         if verbose and self.rank == 0:
             print(f"[OK] MAPPO (MI355X) initialised: obs {self.obs_dim}, state {self.state_dim}, action {self.action_dim}, "
                   f"agents {self.n_agents}, envs/GPU {self.n_envs}, device {self.device}")
@@ -105,12 +108,19 @@ class MAPPOTrainer:
         total_reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
         m.overlap_value = bool(record_buffer) and self.overlap_value
         try:
+            prof = self.profile_events
+            stream = torch.cuda.current_stream(self.device) if prof is not None else None
             for t in range(T):
                 slot = base + t if record_buffer else 0
+                if prof is not None:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record(stream)
                 m.record_and_act(slot, env.obs, env.active, env.rank, self.placement, self.resource, explore=explore,
                                  noise=noise, seed=self.seed, episode=self.policy_episode, env_offset=self.env_offset,
                                  rng_step=t, totals=tot[par], totals_next=tot[par ^ 1])
                 par ^= 1
+                if prof is not None:
+                    ev[1].record(stream)
                 env.bind_obs(ro.obs_slice(base + t + 1) if ro.by_reference else None, tot[par])
                 if record_buffer:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None,
@@ -118,6 +128,9 @@ class MAPPOTrainer:
                 else:
                     env.step(self.placement, self.resource, tape=tapes[t + 1] if tapes is not None else None)
                     total_reward += env.reward
+                if prof is not None:
+                    ev[2].record(stream)
+                    prof.append(ev)
         finally:
             m.overlap_value = False
             m.join_value()
