@@ -28,6 +28,7 @@ __device__ inline uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
 // free of its large-argument path.
 __device__ inline void em_sincos2pi(float u, float& s, float& c)
 {
+#pragma clang fp contract(fast)   // the float32 translation units' mode, also when included where contraction is off (edge_env.hip)
     const float j = rintf(4.0f * u);                       // 0..4
     const float x = 6.2831853071795865f * (u - 0.25f * j); // |x| <= pi/4
     const float z = x * x;
@@ -51,6 +52,7 @@ __device__ inline void em_sincos2pi(float u, float& s, float& c)
 // two standard normals from two 32-bit words (Box-Muller, float32); oracle/philox_ref.box_muller restates it
 __device__ inline void em_box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
 {
+#pragma clang fp contract(fast)
     const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float rad = sqrtf(-2.0f * logf(u1));
@@ -65,6 +67,7 @@ __device__ inline void em_box_muller(uint32_t a, uint32_t b, float& z0, float& z
 // result needs (the relative error near 0, where libm's tanh takes a separate path, does not matter after the + 1).
 __device__ inline float em_resource_share(float raw)
 {
+#pragma clang fp contract(fast)
     const double x = (double)raw;
     const double ax = fabs(x);
     double th = 1.0;

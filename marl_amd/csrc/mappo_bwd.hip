@@ -803,7 +803,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rb = tile * 16 + 4 * s + q;
-            const float* xrow = STAGE ? xt + (4 * s + q) * K1 : a.x + (rb < a.n_rows ? rb : 0) * a.ldx;
+            const float* xrow = xt + (4 * s + q) * K1;
+            if constexpr (!STAGE && !PREFETCH) {          // wide inputs whose rows cannot be staged (K1 % 4 != 0)
+                int64_t src_ = rb < a.n_rows ? rb : 0;
+                if (a.x_rows) src_ = rb < a.n_rows ? (int64_t)a.x_rows[src_] : 0;   // states held by reference
+                xrow = a.x + src_ * a.ldx;
+            }
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const int i = 16 * u + c;

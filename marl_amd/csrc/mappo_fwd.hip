@@ -22,6 +22,14 @@
 #include "em_common.h"
 #include "em_policy_math.h"
 
+#ifdef EM_STAMP_FWD
+__device__ unsigned long long fwd_stamps[16];
+#define FSTAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) fwd_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+#include "em_actor_tile.h"
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -54,15 +62,6 @@ struct FwdArgs {
     float norm_mean, norm_scale;
 };
 
-enum { P_NOISE = 8 };
-
-#ifdef EM_STAMP_FWD
-__device__ unsigned long long fwd_stamps[16];
-#define FSTAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) fwd_stamps[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#endif
-
 // Policy epilogue of one 16-row tile in accumulator layout (y[r] = mean[row c][o = 4q + r]): Gaussian sample + log-prob
 // (mappo_algorithm.py:62-71,209-213) and the trainer's action formatting (mappo_trainer.py:125-158), scattered into the dense
 // environment action arrays.  All 64 lanes of the wavefront must call it (lane shuffles).  `grow`: entry index of the row.
@@ -80,66 +79,22 @@ __device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y,
                                                 const int64_t grow, const int q, const int c, const int O, const float (&ls_)[4],
                                                 const float (&sd_)[4])
 {
-    // ---- policy epilogue ---------------------------------------------------------------------
+    // ---- policy epilogue: the arithmetic is policy_sample (em_actor_tile.h), the scatter is here --------------
     const int n = a.n_nodes;
     const int env = valid ? c_env : 0;
     const int agent = valid ? c_agent : 0;
-    float act[4];
-    float lp = 0.0f;
-    float best = -__builtin_inff();
-    int best_i = 1 << 20;
-    bool all_zero = true;
-    uint4 rnd = make_uint4(0, 0, 0, 0);
-    if (a.explore && !a.noise)
-        rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step, (P_NOISE << 24) | ((uint32_t)agent << 4) | (uint32_t)q,
-                      a.seed_lo, a.seed_hi);
-    FSTAMP(9);
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.explore && !a.noise) { em_box_muller(rnd.x, rnd.y, z[0], z[1]); em_box_muller(rnd.z, rnd.w, z[2], z[3]); }
-    FSTAMP(10);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * q + r;
-        const bool on = o < O;
-        float v = y[r];
-        if (a.explore && on) {
-            const float ls = ls_[r], sd = sd_[r];
-            const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
-            v = y[r] + e * sd;                                  // rsample, mappo_algorithm.py:65
-            const float d = v - y[r];
-            lp += -(d * d) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f;   // Normal.log_prob
-        }
-        act[r] = v;
-        if (on && o < n) {
-            if (fabsf(v) > 1e-8f) all_zero = false;
-            if (v > best) { best = v; best_i = o; }
-        }
-    }
-    FSTAMP(11);
-    // combine the four lanes (q = 0..3) that share a batch row
-#pragma unroll
-    for (int m = 16; m <= 32; m <<= 1) {
-        lp += __shfl_xor(lp, m);
-        const float ob = __shfl_xor(best, m);
-        const int oi = __shfl_xor(best_i, m);
-        const int oz = __shfl_xor((int)all_zero, m);
-        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-        all_zero = all_zero && (oz != 0);
-    }
-    FSTAMP(12);
-    // resource share from component n (mappo_trainer.py:148-152): tanh in float64, result float32
-    const int src = c + 16 * (n >> 2);
-    const float raw = __shfl(act[0], src) * (float)((n & 3) == 0) + __shfl(act[1], src) * (float)((n & 3) == 1) +
-                      __shfl(act[2], src) * (float)((n & 3) == 2) + __shfl(act[3], src) * (float)((n & 3) == 3);
-    const float share = em_resource_share(raw);
-    FSTAMP(13);
+    PolicySampleArgs ps;
+    ps.noise = a.noise; ps.n_nodes = n; ps.explore = a.explore;
+    ps.seed_lo = a.seed_lo; ps.seed_hi = a.seed_hi; ps.episode = a.episode; ps.step = a.step; ps.env_offset = a.env_offset;
+    float act[4], lp, share;
+    int place;
+    policy_sample(ps, y, valid, c_env, c_agent, grow, q, c, O, ls_, sd_, act, lp, place, share);
     if (valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < O) a.ent_action[grow * O + 4 * q + r] = act[r];
         if (q == 0) {
-            a.ent_logp[grow] = a.explore ? lp : 0.0f;          // eval: log_prob = 0 (mappo_algorithm.py:218)
-            const int place = all_zero ? 0 : best_i % n;
+            a.ent_logp[grow] = lp;
             a.placement[(int64_t)env * n + agent] = place;
             a.resource[(int64_t)env * n + agent] = share;
         }

@@ -301,3 +301,60 @@ def test_one_launch_index_and_policy_rejects_what_it_cannot_do():
     copies = RolloutStorage(8, 10, 5, tr.device, by_reference=False)
     assert call(copies, torch.zeros(8, 10, 14, device="cuda"), tot) != 0         # states copied: the two-call path
     assert b"by reference" in L.em_last_error()
+
+
+@pytest.mark.parametrize("n_nodes", [5, 7, 9, 10])
+def test_update_gradients_against_torch_autograd_for_other_node_counts(n_nodes):
+    """One epoch of update() on a recorded batch (states by reference) against torch autograd in float64 on the same buffers,
+    for critic input widths on every path of the backward kernel: 45 (three 16-wide blocks, register prefetch), 77 and 117
+    (wide, rows not a multiple of four floats: neither staged nor prefetched - this path read the dW1 operand rows without
+    the by-reference indirection until round 3), 140 (staged, two wavefronts per SIMD).  mappo_algorithm.py:292-339."""
+    from marl_amd.config import ENV_CONFIG
+    from marl_amd.trainer import MAPPOTrainer
+    cfg = dict(ENV_CONFIG, episode_length=40)
+    if n_nodes != 10:
+        cfg.update(n_nodes=n_nodes, node_cpu_capacity=list(np.linspace(1.0e9, 3.0e9, n_nodes)))
+    tr = MAPPOTrainer(cfg, seed=11, device="cuda:0", n_envs=300, verbose=False)
+    tr.train_episode(explore=True, record_buffer=True)
+    m = tr.mappo
+    m.num_sgd_iter = 1
+    ro = m.buffer
+    E, S = ro.totals()
+    m.compute_gae()
+    cnt, s1, s2 = m.moments.cpu().numpy()
+    mean, std = s1 / cnt, np.sqrt((s2 - s1 * s1 / cnt) / (cnt - 1))
+    f64 = lambda t: t.detach().clone().double()  # noqa: E731
+
+    def mlp(x, p):
+        h = torch.relu(x @ p[0].t() + p[1])
+        h = torch.relu(h @ p[2].t() + p[3])
+        return h @ p[4].t() + p[5]
+
+    # actor: ratio == 1 in the first epoch, so the clipped surrogate's gradient is that of -mean(adv_n * ratio)
+    a_names = [k for k, _ in m.actor.named_parameters()]
+    a_par = {k: f64(p).requires_grad_(True) for k, p in m.actor.named_parameters()}
+    adv = (f64(ro.t["ent_adv"][:E]) - mean) / (std + 1e-8)
+    act, lp_old = f64(ro.t["ent_action"][:E]), f64(ro.t["ent_logp"][:E])
+    ls = a_par["log_std"]
+    mu = mlp(f64(ro.t["ent_obs"][:E]), [a_par[k] for k in a_names if k != "log_std"])
+    lp = (-(act - mu) ** 2 / (2 * torch.exp(ls) ** 2) - ls - 0.5 * np.log(2 * np.pi)).sum(-1)
+    ratio = torch.exp(lp - lp_old)
+    loss_a = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean() - 0.01 * (0.5 + 0.5 * np.log(2 * np.pi) + ls).sum()
+    loss_a.backward()
+    # critic: value of every entry's state against the entry's return (ValueNormalizer is the identity up to 1e-8)
+    c_names = [k for k, _ in m.critic.named_parameters()]
+    c_par = {k: f64(p).requires_grad_(True) for k, p in m.critic.named_parameters()}
+    v = mlp(f64(ro.state_rows(S)), [c_par[k] for k in c_names]).squeeze(1)
+    first, k = ro.t["st_first"][:S].long(), ro.t["st_k"][:S].long()
+    se = 0.0
+    for j in range(int(k.max())):
+        has = k > j
+        se = se + ((v[has] - f64(ro.t["ent_ret"][(first + j)[has]]) / np.sqrt(1 + 1e-8)) ** 2).sum()
+    (0.5 * 0.5 * se / E).backward()
+    m.update()
+    for module, par, base in ((m.actor, a_par, 0), (m.critic, c_par, m.n_actor)):
+        for name, p in par.items():
+            off, count = module._slices[name]
+            got = m.flat_grads[base + off:base + off + count].double().view(p.shape)
+            scale = float(p.grad.abs().max())
+            assert float((got - p.grad).abs().max()) <= 2e-5 * max(scale, 1e-3), (name, scale)
