@@ -498,6 +498,15 @@ int em_gae_agents(int64_t n_envs, int32_t horizon, int32_t n_agents, const doubl
                   const uint8_t *k_tb, const int32_t *first_tb, const int32_t *ent_agent, const float *ent_value,
                   double gamma, double lam, double *chain_state, float *ent_adv, float *ent_ret, void *stream);
 
+/* Groups n_rows rows by key in [0, n_groups) (entry -> the learner that owns it: the reference trains one PPO learner per
+ * agent, MRRL.PY:611-638) for the grouped kernels above: group_off [n_groups + 1] (int64) and perm [n_rows] (position ->
+ * row), STABLE (rows of a group keep their order, so every learner sums in the same order from run to run).  A counting sort
+ * in four short launches; scratch: em_group_index_scratch_ints(n_rows, n_groups) int32, need not be zeroed.  n_groups <= 1024,
+ * n_rows < 2^31; keys outside the range are clamped into it. */
+int64_t em_group_index_scratch_ints(int64_t n_rows, int32_t n_groups);
+int em_group_index(const int32_t *key, int64_t n_rows, int32_t n_groups, int64_t *group_off, int32_t *perm, int32_t *scratch,
+                   void *stream);
+
 /* MAPPO's central critic on the scaled topology (MAPPOCritic, mappo_algorithm.py:74-90, on the concatenated state of
  * mappo_trainer.py:101-123): D*width -> 64 -> 64 -> 1 with the first layer evaluated sparsely over the deciders that
  * hold a task (absent deciders are zero rows of the state).  Parameters in torch.nn.Linear layout; w1 is [64][ldw],

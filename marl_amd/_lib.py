@@ -159,6 +159,10 @@ def lib() -> C.CDLL:
     L.em_rollout_policy_step.argtypes = [C.POINTER(EmRollout), C.c_int32, vp, vp, vp, vp, vp, C.POINTER(EmMlp3), vp, vp, i32, u64,
                                          C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.em_rollout_policy_step.restype = C.c_int
+    L.em_group_index_scratch_ints.argtypes = [i64, i32]
+    L.em_group_index_scratch_ints.restype = i64
+    L.em_group_index.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+    L.em_group_index.restype = C.c_int
     L.em_value_step.argtypes = [C.POINTER(EmRollout), C.c_int32, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]
     L.em_value_step.restype = C.c_int
     L.em_value_all.argtypes = [C.POINTER(EmRollout), i64, C.POINTER(EmMlp3), C.c_float, C.c_float, vp]

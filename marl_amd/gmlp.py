@@ -59,13 +59,20 @@ class GroupedMLP:
 
 
 def group_index(agent: torch.Tensor, n_groups: int):
-    """Stable grouping of rows by network: (group_off int64 [G+1], perm int32 [rows]).  torch's stable sort keeps the
-    original order inside a group, so summation orders (and hence results) are reproducible."""
-    order = torch.sort(agent.to(torch.int64), stable=True).indices
-    counts = torch.bincount(agent.to(torch.int64), minlength=n_groups)
-    off = torch.zeros(n_groups + 1, dtype=torch.int64, device=agent.device)
-    off[1:] = torch.cumsum(counts, 0)
-    return off, order.to(torch.int32).contiguous()
+    """Stable grouping of rows by network: (group_off int64 [G+1], perm int32 [rows]); rows of a group keep their order, so
+    summation orders (and hence results) are reproducible.  ``em_group_index``: a counting sort on the device."""
+    if agent.device.type != "cuda":
+        raise RuntimeError("group_index runs on an MI355X (device='cuda:N'); there is no CPU path")
+    key = agent if agent.dtype == torch.int32 and agent.is_contiguous() else agent.to(torch.int32).contiguous()
+    rows = int(key.numel())
+    L = _lib.lib()
+    off = torch.empty(n_groups + 1, dtype=torch.int64, device=agent.device)
+    perm = torch.empty(rows, dtype=torch.int32, device=agent.device)
+    scratch = torch.empty(max(1, int(L.em_group_index_scratch_ints(rows, n_groups))), dtype=torch.int32, device=agent.device)
+    with torch.cuda.device(agent.device):
+        _lib.check(L.em_group_index(key.data_ptr() if rows else None, rows, int(n_groups), off.data_ptr(),
+                                    perm.data_ptr() if rows else None, scratch.data_ptr(), _stream(agent.device)), "em_group_index")
+    return off, perm
 
 
 def _ptr(t):

@@ -214,3 +214,26 @@ def test_gae_of_independent_learners():
                                         t_v.data_ptr(), 0.99, 0.95, state.data_ptr(), adv.data_ptr(), ret.data_ptr(), None))
     torch.cuda.synchronize()
     assert np.array_equal(adv.cpu().numpy(), want_adv) and np.array_equal(ret.cpu().numpy(), want_ret)
+
+
+@pytest.mark.parametrize("rows,groups", [(0, 4), (1, 1), (63, 5), (2048, 256), (2049, 256), (100_003, 7), (1_500_000, 256),
+                                         (300_000, 1000), (5_000_000, 64)])
+def test_group_index_is_the_stable_sort(rows, groups):
+    """em_group_index (device counting sort: group offsets + position -> row permutation for the grouped kernels, one PPO
+    learner per agent as in MRRL.PY:611-638) against torch's stable sort and bincount: identical, i.e. rows of a group keep
+    their order; ragged tails, a single group, more groups than a wavefront has lanes, empty input."""
+    from marl_amd import gmlp
+    gen = torch.Generator().manual_seed(rows + groups)
+    key = torch.randint(0, groups, (rows,), generator=gen, dtype=torch.int32)
+    if rows > 10:      # an empty group and a run of equal keys across a 64-row pass boundary
+        key[key == groups // 2] = 0
+        key[40:90] = groups - 1
+    key = key.to(DEV)
+    off, perm = gmlp.group_index(key, groups)
+    want_perm = torch.sort(key.to(torch.int64), stable=True).indices.to(torch.int32)
+    want_off = torch.zeros(groups + 1, dtype=torch.int64, device=DEV)
+    want_off[1:] = torch.cumsum(torch.bincount(key.to(torch.int64), minlength=groups), 0)
+    assert torch.equal(off, want_off)
+    assert torch.equal(perm, want_perm)
+    off8, perm8 = gmlp.group_index(key.to(torch.int8) if groups <= 127 else key.to(torch.int64), groups)    # other key dtypes
+    assert torch.equal(off8, want_off) and torch.equal(perm8, want_perm)
