@@ -55,7 +55,8 @@ out["kernel_signature"] = signature(KERNELS["4096"][1])
 out["signatures"] = {k: d["kernel_signature"] for k, d in detail.items()}
 out["measured"] = "tools/measure_traffic.sh, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + time.strftime("%Y-%m-%d")
 out["detail"] = detail
-out["note"] = ("HBM bytes per launch; read side = 2 x FETCH_SIZE (gfx950 correction for 16-B/lane streaming loads; narrower "
-               "loads such as the 4-B/lane action reads are uncalibrated), write side = WRITE_SIZE")
+out["note"] = ("HBM bytes per launch; read side = 2 x FETCH_SIZE (gfx950: the counter tallies 128-byte requests at 64 bytes; "
+               "calibrated for 4-, 8- and 16-byte-per-lane loads with tools/calib_fetch.hip, profiles/r03_fetch_calibration.txt), "
+               "write side = WRITE_SIZE")
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
