@@ -21,6 +21,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_lanes.h"
 #include "em_policy_math.h"
 
 #ifndef EM_GBWD_SPLIT_ACTOR
@@ -167,7 +168,10 @@ struct NoHook { __device__ void operator()() const {} };
 // PER_TILE: the weight fragments are re-read from LDS for every tile (the base address passes through an empty asm, so
 // the compiler cannot hoist the 400-odd loop-invariant reads out of the caller's tile loop into registers, or, with two
 // wavefronts per SIMD and 256 registers, into scratch)
-template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false>
+// HEAD1 (value networks, one output): the third layer on the vector ALU - v = b3 + w3 . h2 from the sixteen h2 values the
+// lane holds (four partial sums, two lane exchanges), in y[0][0] on every lane of the row - instead of a chain of sixteen
+// dependent MFMAs of which 1/16 is used.
+template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false, bool HEAD1 = false>
 __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
                                     f32x4 (&y)[OT], Hook after_l1 = Hook())
 {
@@ -225,6 +229,21 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+    if constexpr (HEAD1) {
+        static_assert(OT == 1, "one output tile");
+        float ps[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float w[4];
+            frag(L::W3, t, w);                            // row 0 of W3, features 16t + 4q + 0..3
+            ps[t] = w[0] * h2[t][0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) ps[t] = fmaf(w[r], h2[t][r], ps[t]);
+        }
+        y[0][0] = em_rows_sum((ps[0] + ps[1]) + (ps[2] + ps[3])) + lds[L::B3];
+        y[0][1] = 0.0f; y[0][2] = 0.0f; y[0][3] = 0.0f;
+        return;
+    }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
         load_x_frag<KU, KC>(a, grow, valid, q, xb);
         f32x4 h1[4], h2[4], y[OT];
         GSTAMP(3);
-        forward_tile<KU, OT, NoHook, (NW > 4)>(lds, xb, q, c, h1, h2, y);
+        forward_tile<KU, OT, NoHook, (NW > 4), (MODE == MODE_VALUE && OT == 1)>(lds, xb, q, c, h1, h2, y);
         GSTAMP(4);
 
         if constexpr (MODE == MODE_PLAIN) {
@@ -548,8 +567,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 __builtin_amdgcn_s_waitcnt(0);            // the next tile has landed (and this tile's values are in registers)
                 post_flag(F_XREADY, k + 2);
                 // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b], as soon as tile k's loss is known
+                if constexpr (ACTOR) {
                 wait_flag(F_READY3, k + 1);
-                {
                     float tb[4][4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -603,6 +622,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 }
             out[HID * K1 + lane] = gb1;
             const int o_w3g = HID * K1 + HID + HID * HID + HID;
+            if constexpr (ACTOR)
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -665,7 +685,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             }
         };
         GBSTAMP(1);
-        forward_tile<KU, OT>(lds, xb, q, c, h1, h2, y, fetch_actions);
+        forward_tile<KU, OT, decltype(fetch_actions), false, !ACTOR>(lds, xb, q, c, h1, h2, y, fetch_actions);
 
         GBSTAMP(2);
         // ---- loss and dL/dy in accumulator layout: dy[ot][r] = d/d out[row c][o = 16 ot + 4q + r] ------------
@@ -688,8 +708,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                     dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
                 }
             }
-            lp += __shfl_xor(lp, 16);
-            lp += __shfl_xor(lp, 32);
+            lp = em_rows_sum(lp);
             float g_lp = 0.0f;
             if (valid) {
                 const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
@@ -731,7 +750,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         }
 
         GBSTAMP(3);
-        if constexpr (SPLIT) {                         // dW3's operands to the gradient wavefront
+        if constexpr (SPLIT && ACTOR) {                // dW3's operands to the gradient wavefront
             wait_flag(F_SDONE3, kt);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -747,23 +766,39 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         GBSTAMP(4);
         // ---- backward through layers 3 and 2 ------------------------------------------------------------------
         f32x4 dz2[4], dz1[4];
+        if constexpr (ACTOR) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dz2[t] = zero4;
+            for (int t = 0; t < 4; ++t) dz2[t] = zero4;
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-            gb3[ot] += dy[ot];
+            for (int ot = 0; ot < OT; ++ot) {
+                gb3[ot] += dy[ot];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 16 ot + 4q + r
+                for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 16 ot + 4q + r
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + 4 * q + r) * S2 + 16 * t + c], dy[ot][r],
-                                                                  dz2[t], 0, 0, 0);
-        }
+                    for (int t = 0; t < 4; ++t)
+                        dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + 4 * q + r) * S2 + 16 * t + c], dy[ot][r],
+                                                                      dz2[t], 0, 0, 0);
+            }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
-            dz1[t] = zero4;
+                for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
+                dz1[t] = zero4;
+            }
+        } else {
+            // value head on the vector ALU (see forward_tile<.., HEAD1>): dH2 = w3 * dv through the ReLU, and dW3 accumulates
+            // dv * h2 per lane (row c's share; the sixteen rows' lanes are summed when the slab row is written)
+            gb3[0] += dy[0];
+            const float dv = em_rows_sum(dy[0][0]);       // dL/dv of row c: only the lane with q = 0 holds it, the others 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gW3[0][t][r] = fmaf(dv, h2[t][r], gW3[0][t][r]);
+                    dz2[t][r] = h2[t][r] > 0.0f ? lds[L::W3 + 16 * t + 4 * q + r] * dv : 0.0f;
+                }
+                dz1[t] = zero4;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             __builtin_amdgcn_wave_barrier();
         };
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]
-        if constexpr (!SPLIT) {
+        if constexpr (!SPLIT && ACTOR) {
         transpose64(h2, tr_b, nullptr);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
@@ -902,7 +937,19 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
         }
-    if constexpr (!SPLIT) {
+    if constexpr (!ACTOR) {
+        // value head: gW3[0][t][r] is this lane's (row c) share of dW3[0][16t + 4q + r]; sum the 16 rows' lanes (fixed order)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = gW3[0][t][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+                if (c == 0) out[o_w3 + 16 * t + 4 * q + r] = v;
+            }
+        for (int i = HID + lane; i < O * HID; i += 64) out[o_w3 + i] = 0.0f;    // only output 0 enters the value loss
+    } else if constexpr (!SPLIT) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
 #pragma unroll

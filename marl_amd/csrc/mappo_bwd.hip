@@ -16,6 +16,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_lanes.h"
 
 namespace {
 
@@ -154,7 +155,9 @@ __device__ unsigned long long bwd_stamps[2][16];
         bst_prev = now_;                                                                                 \
     } while (0)
 #else
-#define BSTAMP(i) do { } while (0)
+// the phase boundaries of a tile double as scheduling fences in the critic: left free, the scheduler mixes the phases
+// of the value-head variant and the kernel loses what the shorter chain gains (19.1 against 17.7 ms per epoch, measured)
+#define BSTAMP(i) do { if constexpr (!ACTOR) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 template <int KU, bool ACTOR, bool STAGE = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd_kernel(const BwdArgs a)
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
     f32x4 bias3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
+    const float b3_0 = a.net.b3[0];
 
     // gradient accumulators (per wavefront, whole launch)
     f32x4 gW1[4][KU], gW2[4][4], gW3[4], gb3, gls;
@@ -561,8 +565,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
                     for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], h1[u][r], h2[t], 0, 0, 0);
                 EM_SB();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {      // last batch: layer 3's fragments, aw[t] = its batch t
-                    if (u < 3) ldW2(u + 1, t, h, aw[t]); else ldW3(t, h, aw[t]);
+                for (int t = 0; t < 4; ++t) {      // last batch: layer 3's fragments, aw[t] = its batch t (critic: dZ1's first)
+                    if (u < 3) ldW2(u + 1, t, h, aw[t]);
+                    else if constexpr (ACTOR) ldW3(t, h, aw[t]);
+                    else ldW2T(0, t, h, aw[t]);
                 }
                 EM_SB();
             }
@@ -572,21 +578,36 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
         y = bias3;
+        // The critic's head has ONE output: as a 16-wide MFMA tile its forward, dH2 and dW3 products are 48 matrix
+        // instructions of which 1/16 is used, a chain of 16 dependent MFMAs in the forward, and two transposes (dY, H2)
+        // for dW3.  On the vector ALU the same three products are 16 multiply-adds each on the values the lane already
+        // holds (h2[t][r]: feature 16t + 4q + r of row c): v = w3 . h2 by four partial sums and two lane exchanges,
+        // dH2 = w3 * dv, and dW3 accumulates dv * h2 per lane (summed over the 16 rows' lanes when the slab row is written).
+        f32x4 w3v[4];
+        float y0 = 0.0f;
+        if constexpr (ACTOR) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][r], h2[u][r], y, 0, 0, 0);
-            EM_SB();
-            ldW3T(u, 0, aw[u]); ldW3T(u, 1, aw[u]);   // the backward pass's first fragments, in flight during the loss
-            if constexpr (!ACTOR) {
-                // normalised returns of the state's first KPRE entries (mappo_algorithm.py:312-313), under the shadow of
-                // this dependent MFMA chain instead of after it
-                if (u == 0) {
-#pragma unroll
-                    for (int j = 0; j < KPRE; ++j) p_ret[j] = (p_ret[j] - a.norm_mean) / a.norm_scale;
-                }
+                for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][r], h2[u][r], y, 0, 0, 0);
+                EM_SB();
+                ldW3T(u, 0, aw[u]); ldW3T(u, 1, aw[u]);   // the backward pass's first fragments, in flight during the loss
+                EM_SB();
             }
-            EM_SB();
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w3v[t] = *reinterpret_cast<const f32x4*>(W3s + 16 * t + boff);
+            // normalised returns of the state's first KPRE entries (mappo_algorithm.py:312-313)
+#pragma unroll
+            for (int j = 0; j < KPRE; ++j) p_ret[j] = (p_ret[j] - a.norm_mean) / a.norm_scale;
+            float ps[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ps[t] = w3v[t][0] * h2[t][0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) ps[t] = fmaf(w3v[t][r], h2[t][r], ps[t]);
+            }
+            y0 = em_rows_sum((ps[0] + ps[1]) + (ps[2] + ps[3])) + b3_0;
         }
 
         BSTAMP(2);
@@ -603,8 +624,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
                     lp += -(d[r] * d[r]) / (2.0f * (sd[r] * sd[r])) - ls[r] - 0.91893853320467274f;
                 }
             }
-            lp += __shfl_xor(lp, 16);
-            lp += __shfl_xor(lp, 32);
+            lp = em_rows_sum(lp);
             float g_lp = 0.0f;
             if (valid) {
                 const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
@@ -629,7 +649,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
             }
         } else {
             if (valid && q == 0) {
-                const float v = y[0];
+                const float v = y0;
                 const int k = p_k;
                 const int64_t first = p_first;
                 float gsum = 0.0f;
@@ -665,23 +685,34 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
         // overtake an earlier read.  The transposed copies take the registers their sources free (no higher peak).
         gb3 += dy;
         f32x4 dz2[4], dz1[4];
+        if constexpr (ACTOR) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dz2[t] = zero4;
+            for (int t = 0; t < 4; ++t) dz2[t] = zero4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {      // dH2^T = W3^T . dY^T, reduction over o = 4q + r
+            for (int h = 0; h < 2; ++h) {      // dH2^T = W3^T . dY^T, reduction over o = 4q + r
 #pragma unroll
-            for (int r = 2 * h; r < 2 * h + 2; ++r)
+                for (int r = 2 * h; r < 2 * h + 2; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], dy[r], dz2[t], 0, 0, 0);
-            EM_SB();
+                    for (int t = 0; t < 4; ++t) dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][r], dy[r], dz2[t], 0, 0, 0);
+                EM_SB();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ldW2T(0, t, h, aw[t]);
-            EM_SB();
+                for (int t = 0; t < 4; ++t) ldW2T(0, t, h, aw[t]);
+                EM_SB();
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
+        } else {
+            const float dv = em_rows_sum(dy[0]);       // dL/dv of row c: only the lane with q = 0 evaluated the loss, the others hold 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gW3[t][r] = fmaf(dv, h2[t][r], gW3[t][r]);                    // dW3[0][16t + 4q + r], this lane's row
+                    dz2[t][r] = h2[t][r] > 0.0f ? w3v[t][r] * dv : 0.0f;          // dH2 through the ReLU
+                }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) dz1[t] = zero4;
         // transposed fragments: tr[t][s] = X[feature 16t + c][batch 4s + q]
@@ -694,6 +725,16 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
             else if (i < 8) tr_y[i - 4] = rrow[4 * (i - 4)];
             else if (i < 24) wcol[(16 * ((i - 8) >> 2) + ((i - 8) & 3)) * TS] = h2[(i - 8) >> 2][(i - 8) & 3];
             else tr_b[(i - 24) >> 2][(i - 24) & 3] = rrow[16 * ((i - 24) >> 2) * TS + 4 * ((i - 24) & 3)];
+        };
+        // critic (no dY / H2 transposes: its dW3 is on the vector ALU): everything dW2 needs goes through the scratch under
+        // dZ1's MFMAs instead - dZ2 out, tr_a and the layer-2 bias row sums back, H1 out, tr_b back (80 LDS instructions)
+        float pv0 = 0.0f, pv1 = 0.0f;
+        auto opV = [&](int i) {
+            if (i < 16) wcol[(16 * (i >> 2) + (i & 3)) * TS] = dz2[i >> 2][i & 3];
+            else if (i < 32) tr_a[(i - 16) >> 2][(i - 16) & 3] = rrow[16 * ((i - 16) >> 2) * TS + 4 * ((i - 16) & 3)];
+            else if (i < 48) { if ((i & 1) == 0) pv0 += rsum[i - 32]; else pv1 += rsum[i - 32]; }
+            else if (i < 64) wcol[(16 * ((i - 48) >> 2) + ((i - 48) & 3)) * TS] = h1[(i - 48) >> 2][(i - 48) & 3];
+            else tr_b[(i - 64) >> 2][(i - 64) & 3] = rrow[16 * ((i - 64) >> 2) * TS + 4 * ((i - 64) & 3)];
         };
         if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
 #pragma unroll
@@ -709,8 +750,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 #pragma unroll
                     for (int t = 0; t < 4; ++t) ldW2T(u + 1, t, h, aw[t]);
                 }
+                if constexpr (ACTOR) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) opB(5 * (2 * u + h) + i);
+                    for (int i = 0; i < 5; ++i) opB(5 * (2 * u + h) + i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) opV(10 * (2 * u + h) + i);
+                }
                 EM_SB();
             }
         }
@@ -723,6 +769,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
         BSTAMP(4);
         // ---- weight gradients: reduction over the 16 batch rows of the tile ---------------------------
         // dW3[o][j] += sum_b dY^T[o][b] H2^T[j][b]; dZ2 leaves for the scratch between its MFMAs
+        if constexpr (ACTOR)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -739,6 +786,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
             for (int j = 0; j < 16; j += 2) { p0 += rsum[j]; p1 += rsum[j + 1]; }
             acc += p0 + p1;
         };
+        if constexpr (ACTOR) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -762,6 +810,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
             for (int s = 0; s < 4; ++s) tr_b[t][s] = rrow[16 * t * TS + 4 * s];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        } else {
+            gb2_l += pv0 + pv1;
+            BSTAMP(5);
+        }
         BSTAMP(6);
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]; dZ1 is transposed (and row-summed: gb1) between the batches
         float pb0 = 0.0f, pb1 = 0.0f;
@@ -857,11 +909,25 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[o_w2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
         }
+    if constexpr (ACTOR) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * q + r < O) out[o_w3 + (4 * q + r) * HID + 16 * t + c] = gW3[t][r];
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < O) out[o_w3 + (4 * q + r) * HID + 16 * t + c] = gW3[t][r];
+    } else {
+        // value head: gW3[t][r] is this lane's (row c) share of dW3[0][16t + 4q + r]; sum the 16 rows' lanes (fixed order)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = gW3[t][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+                if (c == 0) out[o_w3 + 16 * t + 4 * q + r] = v;
+            }
+        for (int i = HID + lane; i < O * HID; i += 64) out[o_w3 + i] = 0.0f;    // only output 0 enters the value loss
+    }
     // bias-type gradients: reduce the 16 lanes that share q (fixed butterfly order)
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) {

@@ -20,6 +20,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_lanes.h"
 #include "em_policy_math.h"
 
 #ifdef EM_STAMP_FWD
@@ -205,12 +206,13 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         }
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) a3[s] = W3s[c * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];
+    for (int s = 0; s < 16; ++s) a3[s] = W3s[(MODE == 2 ? 0 : c) * S2 + 16 * (s >> 2) + 4 * q + (s & 3)];   // value head: row 0 on every lane
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias3[r] = (4 * q + r) < O ? a.net.b3[4 * q + r] : 0.0f;
 
     float pls[4] = {0.f, 0.f, 0.f, 0.f}, psd[4] = {1.f, 1.f, 1.f, 1.f};
     if constexpr (MODE == 1) policy_scales(a, q, O, pls, psd);
+    const float b3_0 = a.net.b3[0];
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t row = tile * 16 + c;          // row relative to row_base
         const bool valid = row < n_rows;
@@ -248,8 +250,22 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
         y = bias3;
+        if constexpr (MODE == 2) {
+            // value head (one output) on the vector ALU: v = b3 + w3 . h2 from the sixteen h2 values the lane holds (four
+            // partial sums, two lane exchanges) instead of a chain of sixteen dependent MFMAs of which 1/16 is used; the
+            // backward kernels (mappo_bwd.hip) evaluate the same expression
+            float ps[4];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], h2[s >> 2][s & 3], y, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                ps[t] = a3[4 * t] * h2[t][0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) ps[t] = fmaf(a3[4 * t + r], h2[t][r], ps[t]);
+            }
+            y[0] = em_rows_sum((ps[0] + ps[1]) + (ps[2] + ps[3])) + b3_0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], h2[s >> 2][s & 3], y, 0, 0, 0);
+        }
         // y[r] = out[row][o = 4q + r]
 
         const int64_t grow = row_base + row;

@@ -10,7 +10,8 @@ from marl_amd.config import ENV_CONFIG  # noqa: E402
 from marl_amd.trainer import MAPPOTrainer  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-tr = MAPPOTrainer(dict(ENV_CONFIG, episode_length=100), seed=0, device="cuda:0", n_envs=B, verbose=False)
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+tr = MAPPOTrainer(dict(ENV_CONFIG, episode_length=T), seed=0, device="cuda:0", n_envs=B, verbose=False)
 L = _lib.lib()
 tr.train_episode(explore=True, record_buffer=True)
 torch.cuda.synchronize()
