@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
     if constexpr (ACTOR) {
         if (threadIdx.x < 16 * OT) {
             const float sd = expf(lds[L::LS + threadIdx.x]);
-            den_t[threadIdx.x] = 2.0f * (sd * sd);
+            den_t[threadIdx.x] = 0.5f * (1.0f / (sd * sd));   // 1 / (2 sd^2): the log-density's quotient as a product (<= 1 ulp per term)
             iv_t[threadIdx.x] = 1.0f / (sd * sd);
         }
         __syncthreads();
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                     float d = 0.0f;
                     if (o < O && valid) {
                         d = p_act[ot][r] - y[ot][r];
-                        lp += -(d * d) / den4[r] - ls4[r] - HALF_LOG_2PI;
+                        lp += -(d * d) * den4[r] - ls4[r] - HALF_LOG_2PI;
                     }
                     dy[ot][r] = d;                                          // holds (action - mu) until g_lp is known
                 }
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             float g_lp = 0.0f;
             if (valid) {
                 const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
-                const float ratio = expf(lp - p_old);                       // :306
+                const float ratio = __expf(lp - p_old);                     // :306 (|argument| << 1: the hardware exp2 is within 2 ulp)
                 const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
                 const float rc = fminf(fmaxf(ratio, lo), hi);
                 const float su1 = ratio * A, su2 = rc * A;                  // :307-308

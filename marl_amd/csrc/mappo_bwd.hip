@@ -241,6 +241,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
     float cnt_sum = 0.0f;
 
     float adv_mean = 0.0f, adv_den = 1.0f, sd[4] = {1.f, 1.f, 1.f, 1.f}, ls[4] = {0.f, 0.f, 0.f, 0.f};
+    float ivar[4] = {1.f, 1.f, 1.f, 1.f};     // 1 / sd^2: the log-density's quotients as products (<= 1 ulp per term)
     if constexpr (ACTOR) {
         const double n = a.moments[0], s1 = a.moments[1], s2 = a.moments[2];
         const double mean = s1 / n;
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < O) { ls[r] = a.log_std[4 * q + r]; sd[r] = expf(ls[r]); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ivar[r] = 1.0f / (sd[r] * sd[r]);
     }
 
     float ent_row = 0.0f;                              // entropy of the state-independent Gaussian, the same for every row
@@ -621,14 +624,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
                 d[r] = 0.0f;
                 if (o < O && valid) {
                     d[r] = p_act[r] - y[r];
-                    lp += -(d[r] * d[r]) / (2.0f * (sd[r] * sd[r])) - ls[r] - 0.91893853320467274f;
+                    lp += -(d[r] * d[r]) * (0.5f * ivar[r]) - ls[r] - 0.91893853320467274f;
                 }
             }
             lp = em_rows_sum(lp);
             float g_lp = 0.0f;
             if (valid) {
                 const float A = (p_adv - adv_mean) / adv_den;               // mappo_algorithm.py:293
-                const float ratio = expf(lp - p_old);                       // :306
+                const float ratio = __expf(lp - p_old);                     // :306 (|argument| << 1: the hardware exp2 is within 2 ulp)
                 const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
                 const float rc = fminf(fmaxf(ratio, lo), hi);
                 const float su1 = ratio * A, su2 = rc * A;                  // :307-308
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
             for (int r = 0; r < 4; ++r) {
                 const int o = 4 * q + r;
                 if (o < O && valid) {
-                    const float iv = 1.0f / (sd[r] * sd[r]);
+                    const float iv = ivar[r];
                     dy[r] = g_lp * d[r] * iv;                               // d logp / d mu
                     gls[r] += g_lp * (d[r] * d[r] * iv - 1.0f) - a.ecoef * a.inv_L;   // d logp / d log_std ; entropy bonus
                 }
