@@ -10,6 +10,7 @@
 #include <cstdint>
 
 #include "edgemarl.h"
+#include "em_lanes.h"
 #include "em_policy_math.h"
 
 #ifndef FSTAMP
@@ -72,12 +73,14 @@ __device__ __forceinline__ void policy_sample(const PolicySampleArgs& a, const f
     }
     FSTAMP(11);
     // combine the four lanes (q = 0..3) that share a batch row
+    // (row exchanges on the vector ALU, em_lanes.h: eight ds_bpermute round trips per tile before)
 #pragma unroll
     for (int m = 16; m <= 32; m <<= 1) {
-        lp += __shfl_xor(lp, m);
-        const float ob = __shfl_xor(best, m);
-        const int oi = __shfl_xor(best_i, m);
-        const int oz = __shfl_xor((int)all_zero, m);
+        auto other = [&](unsigned v) { return m == 16 ? em_xor16(v, q) : em_xor32(v, q); };
+        lp += __uint_as_float(other(__float_as_uint(lp)));
+        const float ob = __uint_as_float(other(__float_as_uint(best)));
+        const int oi = (int)other((unsigned)best_i);
+        const int oz = (int)other((unsigned)all_zero);
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         all_zero = all_zero && (oz != 0);
     }

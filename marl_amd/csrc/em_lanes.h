@@ -20,4 +20,16 @@ __device__ __forceinline__ float em_rows_sum(float v)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// the value that lane (lane ^ 16) / (lane ^ 32) holds, i.e. __shfl_xor(v, 16) / __shfl_xor(v, 32); q = lane >> 4
+__device__ __forceinline__ unsigned em_xor16(unsigned v, int q)
+{
+    const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // p[0] = {r0, r0, r2, r2}, p[1] = {r1, r1, r3, r3}
+    return (q & 1) ? p[0] : p[1];
+}
+__device__ __forceinline__ unsigned em_xor32(unsigned v, int q)
+{
+    const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // p[0] = {lo, lo}, p[1] = {hi, hi}
+    return (q & 2) ? p[0] : p[1];
+}
+
 }  // namespace
