@@ -519,6 +519,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     __shared__ float s_ratio_all[WAVES_PER_BLOCK][EPW4][64];
     __shared__ int32_t s_pdec_all[WAVES_PER_BLOCK][64];
     __shared__ double s_cap[64], s_icap[64];
+    __shared__ int4 s_rowi_all[WAVES_PER_BLOCK][64];      // observation rows to write: {home | env << 8, queue, slot, -}
+    __shared__ float4 s_rowf_all[WAVES_PER_BLOCK][64];    //                            {data, workload, time left, -}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = SC ? SC : p.S, D = DC ? DC : p.D, w = S + 4;
@@ -749,7 +751,45 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     // observation rows of the new pending deciders (_get_obs, MRRL.PY:307-324), compact, in arrival order
     const double a_rem = a_deadline - t_now;
     const float f_data = (float)a_data, f_wl = (float)a_wl, f_rem = (float)(a_rem > 0 ? a_rem : 0.0);
-    {
+    if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(out.pend_obs) & 15) == 0) {
+        // Rows of w = S + 4 floats are w / 4 aligned 16-byte pieces.  Every new decider publishes its row's parameters at
+        // (rows of the preceding environments of the wavefront) + (its slot); then the wavefront writes all rows of its four
+        // environments piece by piece, 64 pieces per pass (about nine rows = 153 pieces per wavefront at 64 x 256).  One row
+        // at a time - five readlanes, then two passes over the 68 columns, the second with four lanes - was half of the
+        // kernel's instructions.
+        int4* s_rowi = s_rowi_all[wave];
+        float4* s_rowf = s_rowf_all[wave];
+        const int np0 = rl_i(n_pending, 0), np1 = rl_i(n_pending, 16), np2 = rl_i(n_pending, 32), np3 = rl_i(n_pending, 48);
+        const int rb1 = np0, rb2 = rb1 + np1, rb3 = rb2 + np2, n_rows = rb3 + np3;
+        if (is_new) {
+            const int at = (g == 0 ? 0 : g == 1 ? rb1 : g == 2 ? rb2 : rb3) + rank;
+            s_rowi[at] = make_int4(a_home | (g << 8), q_obs, rank, 0);
+            s_rowf[at] = make_float4(f_data, f_wl, f_rem, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int pieces = w >> 2;
+        const uint32_t magic_p = (uint32_t)((0x100000000ull + (uint32_t)pieces - 1u) / (uint32_t)pieces);   // t / pieces for t < 2^16
+        const int n_items = n_rows * pieces;
+        for (int t = lane; t < n_items; t += 64) {
+            const int rr = (int)__umulhi((uint32_t)t, magic_p), m = t - rr * pieces;
+            const int4 pi = s_rowi[rr];
+            const float4 pf = s_rowf[rr];
+            const int h = pi.x & 255, e = pi.x >> 8;
+            const float* ra = s_ratio[e];
+            float v[4];
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                int i = 4 * m + k2 - 5;                 // column c = 4m + k2 >= 5 shows server i, the home server left out
+                i = i < 0 ? 0 : i;
+                v[k2] = ra[i < h ? i : i + 1];
+            }
+            if (m == 0) { v[0] = ra[h]; v[1] = (float)pi.y; v[2] = pf.x; v[3] = pf.y; }
+            if (m == 1) v[0] = pf.z;
+            float* row = out.pend_obs + ((env0 + e) * PCAP + pi.z) * (int64_t)w;
+            *reinterpret_cast<float4*>(row + 4 * m) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
         const uint64_t all_new = __ballot(is_new);
 #pragma unroll
         for (int e = 0; e < EPW4; ++e) {
