@@ -501,6 +501,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES) void scaled_en
 // An environment whose step has more than 16 pending slots or more than 16 arrivals (rare: Poisson means are 1..3, 10 at
 // reset) takes step_one_env on the whole wavefront afterwards.  Bit-identical to scaled_env_kernel.
 constexpr int EPW4 = 4, GW4 = 16;
+#ifdef EMS_STAMP      // cycle stamps of one wavefront of the step kernel (tools/stamp_scaled.py); compiled out of the library
+__device__ unsigned long long ems_stamps[16];
+#define ESTAMP(i) do { if (!RESET && blockIdx.x == 7 && threadIdx.x == 0) ems_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESTAMP(i) do { } while (0)
+#endif
 
 template <bool RESET, int SC = 0, int DC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_env4_kernel(const ScaledParams p, unsigned char* __restrict__ state,
@@ -525,13 +531,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = SC ? SC : p.S, D = DC ? DC : p.D, w = S + 4;
     const int RB = SC ? srec_bytes(SC) : p.rec_bytes;
-    if (threadIdx.x < 64) {
-        s_cap[threadIdx.x] = (int)threadIdx.x < S ? cc->cap[threadIdx.x] : 1.0;
-        s_icap[threadIdx.x] = (int)threadIdx.x < S ? cc->inv_cap[threadIdx.x] : 1.0;
-    }
-    __syncthreads();
+    ESTAMP(0);
+    // the capacity tables are requested first and waited for AFTER the step's own loads are in flight and the first
+    // Philox round is done (one memory round trip per workgroup instead of two in a row: 1.8 k of a step's 17 k cycles)
+    double cap_in = 1.0, icap_in = 1.0;
+    if (threadIdx.x < 64 && (int)threadIdx.x < S) { cap_in = cc->cap[threadIdx.x]; icap_in = cc->inv_cap[threadIdx.x]; }
     const int64_t env0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * EPW4;
-    if (env0 >= p.n_envs) return;                // whole wavefronts leave; nothing below synchronises across wavefronts
+    const bool wave_ok = env0 < p.n_envs;        // a wavefront past the batch shadows environment 0 up to the barrier
+    ESTAMP(1);
     double (*s_load)[64] = s_load_all[wave];
     int32_t (*s_queue)[64] = s_queue_all[wave];
     float (*s_ratio)[64] = s_ratio_all[wave];
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     const bool valid = env < p.n_envs;
     const uint32_t eid = p.env_offset + (uint32_t)env;
     const uint32_t step_no = RESET ? 0u : (uint32_t)p.step_no;
-    const int64_t renv = valid ? env : env0;     // lanes of an absent environment shadow the first one and never store
+    const int64_t renv = valid ? env : (wave_ok ? env0 : 0);     // lanes of an absent environment shadow a real one and never store
     unsigned char* rec = state + renv * (int64_t)RB;
     double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
     int32_t* g_int = reinterpret_cast<int32_t*>(rec + srec_off_int(S));
@@ -605,7 +612,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
             a_dec = is_a ? othz : minez;
         }
     };
+    ESTAMP(2);
     task_round(0);
+    if (threadIdx.x < 64) { s_cap[threadIdx.x] = cap_in; s_icap[threadIdx.x] = icap_in; }
+    __syncthreads();
+    if (!wave_ok) return;                        // whole wavefronts leave; nothing below synchronises across wavefronts
+    ESTAMP(3);
 
     const bool slow = valid && (k_old > GW4 || n_new > GW4);
     const bool fast = valid && !slow;
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
 
     double reward = 0.0;
     int k = 0;
+    ESTAMP(4);
     if constexpr (!RESET) {
         double net_bw = 0.0, net_lat = 0.0, ex_u = 2.0, ex_res = 0.0;
         int ex_tgt = 0;
@@ -638,6 +651,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
                 }
             }
         }
+        ESTAMP(5);
         // ---- placement phase (MRRL.PY:397-438) ----------------------------------------------------------------
         int tgt = tgt_in;
         const bool acting = have && tgt >= 0 && tgt < S;
@@ -665,6 +679,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+        ESTAMP(6);
         // ordered chain over acting slots, the four environments side by side (MRRL.PY:416,437)
         int kmax = k;
         kmax = max(kmax, __shfl_xor(kmax, 16));
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
             __builtin_amdgcn_wave_barrier();
         }
         const int n_viol = __popc((uint32_t)((__ballot(viol) >> gbase) & 0xffffull));
+        ESTAMP(7);
 
         // reward (MRRL.PY:326-338) and episode accumulators (MRRL.PY:463-466); every lane of the group computes its copy
         if (k > 0) {
@@ -710,6 +726,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         n_done_before += k - n_viol;
     }
 
+    ESTAMP(8);
     // ---- load ratios BEFORE this step's decay: server phase over the four environments -----------------------------
     {
         const double cap_me = s_cap[lane], icap_me = s_icap[lane];
@@ -740,6 +757,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
             }
         }
     }
+    ESTAMP(9);
     const bool is_new = has && !dup;
     const uint32_t new_bits = (uint32_t)((__ballot(is_new) >> gbase) & 0xffffull);
     const int rank = __popc(new_bits & below);
@@ -822,6 +840,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    ESTAMP(10);
     // ---- decay, clock, outputs (MRRL.PY:364-375,444-459) ---------------------------------------------------------
     {
         const double cap_me = s_cap[lane];
@@ -867,6 +886,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         out.n_pending[env] = n_pending;
     }
 
+    ESTAMP(11);
     // ---- environments beyond the 16-slot groups: the general path, one at a time on the whole wavefront -------------
     if (slow_bits != 0ull) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -957,10 +977,11 @@ struct ems_handle {
 
 namespace {
 
-// Four environments per wavefront share the lane-sparse instructions (throughput: 104 -> 83 us per step at 65,536
-// environments) but leave a small batch with a quarter of the wavefronts, and a small batch is bound by the latency of
-// one wavefront (20.8 vs 15.6 us at 4,096): one environment per wavefront below 32,768.
-int pick_epw(int64_t n_envs) { return n_envs >= 16384 ? 4 : 1; }   // 26.4 vs 30.4 us at 16,384; 21.8 vs 20.9 us at 8,192
+// Four environments per wavefront share the lane-sparse instructions.  With the rows of a wavefront written piecewise
+// (scaled_env4_kernel) its one-wavefront latency is below the one-environment kernel's at every batch size (MI355X, us per
+// step, four / one environment per wavefront: 12.3 / 15.0 at 4,096, 14.0 / 20.9 at 8,192, 18.0 / 26.8 at 16,384, 62.7 / 104
+// at 65,536), so it is the default; ems_set_envs_per_wave(1) selects scaled_env_kernel (identical results, tested).
+int pick_epw(int64_t n_envs) { (void)n_envs; return 4; }
 
 ScaledParams make_sparams(const ems_handle* h)
 {
@@ -1119,6 +1140,13 @@ int ems_reset(ems_handle* h, int has_seed, uint64_t seed, const ems_step_out* ou
     }
     return em::hip_check(hipGetLastError(), "scaled_env_kernel<reset> launch");
 }
+
+#ifdef EMS_STAMP
+int ems_debug_stamps(unsigned long long* out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ems_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 int ems_step(ems_handle* h, const int32_t* placement, const float* resource, int actions_by_slot, const ems_step_out* out,
              void* stream)
