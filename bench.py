@@ -231,8 +231,8 @@ def mappo_leg(device, rank, world, n_envs, iters=2):
             "rollout": "two launches per step (env step; entry numbering + copy + actor in one kernel), states by reference, "
                        "acting-agent totals from the step kernel, one critic launch per episode (inside rollout_s)",
             "update": "4 epochs x (actor + critic fused forward/loss/backward); the critic kernel runs two wavefronts per SIMD "
-                      "(dW1 and the tile staging in the second one; PMC MFMA busy 0.75 critic / 0.72 actor, "
-                      "profiles/r02_mlp_bwd_pmc_sq.txt)",
+                      "(dW1 and the tile staging in the second one) and its one-output head on the vector ALU; PMC MFMA busy "
+                      "0.73 critic / 0.76 actor, profiles/r03_mlp_bwd_pmc_sq.txt)",
             "collective": "1 fused all-reduce of 19,103 floats per epoch + 3 doubles per update" if world > 1 else "none"}
 
 
