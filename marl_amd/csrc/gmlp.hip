@@ -1078,6 +1078,14 @@ __global__ __launch_bounds__(256) void group_moments_kernel(const float* __restr
 // GAE of independent learners: one chain per (environment, agent) over that agent's own transitions in time order
 // (MAPPO.compute_gae's recursion, mappo_algorithm.py:250-258, with the agent's own value estimates; next_value = 0
 // closes every chain, :284).  One lane per environment walks its steps backwards; chain state lives in `state`.
+#ifndef EM_GAE_SUB
+#define EM_GAE_SUB 16
+#endif
+constexpr int GAE_SUB = EM_GAE_SUB;
+// LDS_STATE: the chain states of the workgroup's 256 / GAE_SUB environments live in LDS (16 D bytes each).  In global memory
+// every step's dependent state load sits BEHIND the look-ahead loads of the following steps in the in-order vmcnt queue, so
+// waiting for it waited for them as well and each of the 1000 steps cost a whole memory round trip, whatever was prefetched.
+template <bool LDS_STATE>
 __global__ __launch_bounds__(256) void gae_agents_kernel(int64_t B, int T, int D, const double* __restrict__ reward_tb,
                                                          const uint8_t* __restrict__ done_tb, const uint8_t* __restrict__ k_tb,
                                                          const int32_t* __restrict__ first_tb, const int32_t* __restrict__ ent_agent,
@@ -1085,20 +1093,27 @@ __global__ __launch_bounds__(256) void gae_agents_kernel(int64_t B, int T, int D
                                                          double* __restrict__ state, float* __restrict__ adv, float* __restrict__ ret)
 {
 #pragma clang fp contract(off)   // the float64 recursion in the reference's operation order, no fused multiply-add
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // GAE_SUB lanes per environment: lane `sub` owns the chains of the agents with d % GAE_SUB == sub (chains of different
+    // agents never meet), which gives the launch GAE_SUB times the wavefronts to hide the chain-state round trips with
+    // (16,384 environments are a quarter of a wavefront per SIMD at one lane each)
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = gt / GAE_SUB;
+    const int sub = (int)(gt - b * GAE_SUB);
     if (b >= B) return;
-    double* st = state + b * 2 * (int64_t)D;          // {gae, v_next} per agent
-    for (int d = 0; d < 2 * D; ++d) st[d] = 0.0;
+    extern __shared__ __align__(16) double st_lds[];
+    double* st = LDS_STATE ? st_lds + (threadIdx.x / GAE_SUB) * 2 * (int64_t)D : state + b * 2 * (int64_t)D;   // {gae, v_next} per agent
+    for (int d = sub; d < D; d += GAE_SUB) { st[2 * d] = 0.0; st[2 * d + 1] = 0.0; }
     // Four dependent memory round trips per step (k -> first -> entry -> chain state) and one lane has nothing else to do
     // while it waits: the next step's {k, first, reward, done} and its first KP entries {agent, value} are requested one step
     // ahead, which leaves the chain-state access as the only exposed one (6.0 -> 2 ms at 16,384 environments x 1000 steps).
     constexpr int KP = 4;
     struct StepIn { int k; int64_t first; double r, nd; int d[KP]; float v[KP]; };
+    // every look-ahead load is unconditional on a clamped address (a load under a per-lane branch makes the compiler wait for
+    // everything in flight where the branch ends); what it fetched beyond the step's k entries is never used
     auto fetch = [&](int t, StepIn& o) {
-        o.k = 0;
-        if (t < 0) return;
-        const int64_t i = (int64_t)t * B + b;
-        o.k = k_tb[i];
+        const int64_t i = (int64_t)(t < 0 ? 0 : t) * B + b;
+        const int kk = k_tb[i];
+        o.k = t < 0 ? 0 : kk;
         o.r = reward_tb[i];
         o.nd = 1.0 - (double)done_tb[i];
         o.first = first_tb[i];
@@ -1106,8 +1121,8 @@ __global__ __launch_bounds__(256) void gae_agents_kernel(int64_t B, int T, int D
     auto fetch_entries = [&](StepIn& o) {
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-            o.d[j] = 0; o.v[j] = 0.0f;
-            if (j < o.k) { o.d[j] = ent_agent[o.first + j]; o.v[j] = ent_value[o.first + j]; }
+            const int64_t e = j < o.k ? o.first + j : 0;
+            o.d[j] = ent_agent[e]; o.v[j] = ent_value[e];
         }
     };
     StepIn cur, nxt, nn;
@@ -1132,6 +1147,7 @@ __global__ __launch_bounds__(256) void gae_agents_kernel(int64_t B, int T, int D
                 d = ent_agent[first + j];
                 v = (double)ent_value[first + j];
             }
+            if (d % GAE_SUB != sub) continue;
             const double delta = r + gamma * st[2 * d + 1] * nd - v;
             const double gae = delta + gamma * lam * nd * st[2 * d];
             st[2 * d] = gae;
@@ -1411,9 +1427,14 @@ int em_gae_agents(int64_t n_envs, int32_t horizon, int32_t n_agents, const doubl
     if (!reward_tb || !done_tb || !k_tb || !first_tb || !ent_agent || !ent_value || !chain_state || !ent_adv || !ent_ret)
         return em::fail(EM_ERR_INVALID, "em_gae_agents: null argument");
     if (n_envs < 1 || horizon < 1 || n_agents < 1) return em::fail(EM_ERR_INVALID, "em_gae_agents: bad sizes");
-    hipLaunchKernelGGL(gae_agents_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_envs,
-                       horizon, n_agents, reward_tb, done_tb, k_tb, first_tb, ent_agent, ent_value, gamma, lam, chain_state,
-                       ent_adv, ent_ret);
+    const dim3 grid((unsigned)((n_envs * GAE_SUB + 255) / 256));
+    const size_t lds = (size_t)(256 / GAE_SUB) * 2 * (size_t)n_agents * sizeof(double);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(gae_agents_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, n_envs, horizon, n_agents, reward_tb,
+                           done_tb, k_tb, first_tb, ent_agent, ent_value, gamma, lam, chain_state, ent_adv, ent_ret);
+    else
+        hipLaunchKernelGGL(gae_agents_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, n_envs, horizon, n_agents, reward_tb,
+                           done_tb, k_tb, first_tb, ent_agent, ent_value, gamma, lam, chain_state, ent_adv, ent_ret);
     return em::hip_check(hipGetLastError(), "gae agents launch");
 }
 
