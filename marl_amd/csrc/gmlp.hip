@@ -171,7 +171,9 @@ struct NoHook { __device__ void operator()() const {} };
 // HEAD1 (value networks, one output): the third layer on the vector ALU - v = b3 + w3 . h2 from the sixteen h2 values the
 // lane holds (four partial sums, two lane exchanges), in y[0][0] on every lane of the row - instead of a chain of sixteen
 // dependent MFMAs of which 1/16 is used.
-template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false, bool HEAD1 = false>
+// PIPE (backward kernels, two wavefronts per SIMD): the fragments of reduction block u + 1 are requested before the MFMAs of
+// block u are issued (a second set of 16 registers), pinned with scheduling fences.
+template <int KU, int OT, class Hook = NoHook, bool PER_TILE = false, bool HEAD1 = false, bool PIPE = false>
 __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 4], int q, int c, f32x4 (&h1)[4], f32x4 (&h2)[4],
                                     f32x4 (&y)[OT], Hook after_l1 = Hook())
 {
@@ -195,6 +197,24 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h1[t][r] = lds[L::B1 + 16 * t + 4 * q + r];
+    if constexpr (PIPE) {
+        float w[2][4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) frag(L::W1 + (16 * t + c) * L::S1, 0, w[0][t]);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            if (u + 1 < KU) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) frag(L::W1 + (16 * t + c) * L::S1, u + 1, w[(u + 1) & 1][t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u & 1][t][r], xb[4 * u + r], h1[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < KU; ++u)
     {   // reduction index outside, accumulator inside: consecutive MFMAs never wait for each other
@@ -206,6 +226,7 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
 #pragma unroll
             for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], xb[4 * u + r], h1[t], 0, 0, 0);
     }
+    }
     after_l1();
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -214,6 +235,24 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
             h1[t][r] = fmaxf(h1[t][r], 0.0f);
             h2[t][r] = lds[L::B2 + 16 * t + 4 * q + r];
         }
+    if constexpr (PIPE) {
+        float w[2][4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) frag(L::W2 + (16 * t + c) * L::S2, 0, w[0][t]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u + 1 < 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) frag(L::W2 + (16 * t + c) * L::S2, u + 1, w[(u + 1) & 1][t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u & 1][t][r], h1[u][r], h2[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
     {
@@ -224,6 +263,7 @@ __device__ inline void forward_tile(const float* lds_in, const float (&xb)[KU * 
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], h1[u][r], h2[t], 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -419,6 +459,9 @@ __device__ unsigned long long gbwd_stamps[2][16];
 #define GBSTAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if ((i) > 0) gb_acc[i] += (unsigned)(n_ - gb_prev); else gb_acc[0] += 1; gb_prev = n_; } while (0)
 #else
 #define GBSTAMP(i) do { } while (0)
+#endif
+#ifndef EM_GBWD_PIPE
+#define EM_GBWD_PIPE true
 #endif
 template <int KU, int OT, bool ACTOR, bool STAGE = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GArgs a)
@@ -685,7 +728,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
             }
         };
         GBSTAMP(1);
-        forward_tile<KU, OT, decltype(fetch_actions), false, !ACTOR>(lds, xb, q, c, h1, h2, y, fetch_actions);
+        forward_tile<KU, OT, decltype(fetch_actions), false, !ACTOR, EM_GBWD_PIPE>(lds, xb, q, c, h1, h2, y, fetch_actions);
 
         GBSTAMP(2);
         // ---- loss and dL/dy in accumulator layout: dy[ot][r] = d/d out[row c][o = 16 ot + 4q + r] ------------
@@ -770,14 +813,30 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
 #pragma unroll
             for (int t = 0; t < 4; ++t) dz2[t] = zero4;
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                gb3[ot] += dy[ot];
+            for (int ot = 0; ot < OT; ++ot) gb3[ot] += dy[ot];
+            // dH2^T = W3^T . dY^T, reduction over o = 16 ot + 4q + r.  The four fragments of the NEXT reduction index are
+            // requested before the four MFMAs of this one are issued (left to itself the compiler's schedule was "read two
+            // words, wait for LDS, two MFMAs", forty times: every LDS latency exposed)
+            {
+                const float* wcol3 = lds + L::W3 + (4 * q) * S2 + c;
+                float fa[4], fb[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)        // dH2^T = W3^T . dY^T, reduction over o = 16 ot + 4q + r
+                for (int t = 0; t < 4; ++t) fa[t] = wcol3[16 * t];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W3 + (16 * ot + 4 * q + r) * S2 + 16 * t + c], dy[ot][r],
-                                                                      dz2[t], 0, 0, 0);
+                for (int i = 0; i < 4 * OT; ++i) {
+                    const int ot = i >> 2, r = i & 3;
+                    float (&cur_)[4] = (i & 1) ? fb : fa;
+                    float (&nxt_)[4] = (i & 1) ? fa : fb;
+                    if (i + 1 < 4 * OT) {
+                        const int ot1 = (i + 1) >> 2, r1 = (i + 1) & 3;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) nxt_[t] = wcol3[(16 * ot1 + r1) * S2 + 16 * t];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur_[t], dy[ot][r], dz2[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -800,12 +859,25 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 dz1[t] = zero4;
             }
         }
+        {   // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r; fragments one reduction index ahead, as above
+            const float* wcol2 = lds + L::W2 + (4 * q) * S2 + c;
+            float fa[4], fb[4];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {     // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r
-            const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+            for (int t = 0; t < 4; ++t) fa[t] = wcol2[16 * t];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[L::W2 + k * S2 + 16 * t + c], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+            for (int s = 0; s < 16; ++s) {
+                float (&cur_)[4] = (s & 1) ? fb : fa;
+                float (&nxt_)[4] = (s & 1) ? fa : fb;
+                if (s + 1 < 16) {
+                    const int k1 = 16 * ((s + 1) >> 2) + ((s + 1) & 3);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nxt_[t] = wcol2[k1 * S2 + 16 * t];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur_[t], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
