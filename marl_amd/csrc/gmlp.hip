@@ -793,6 +793,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
         }
 
         GBSTAMP(3);
+        // (Writing these 36 words under dZ2's MFMAs instead - two per MFMA group - was measured: 23 spilled registers,
+        // 31.4 instead of 27.0 ms per epoch.)
         if constexpr (SPLIT && ACTOR) {                // dW3's operands to the gradient wavefront
             wait_flag(F_SDONE3, kt);
 #pragma unroll
@@ -859,6 +861,21 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 dz1[t] = zero4;
             }
         }
+        // HIDE (two-wavefront critic; the actor kernel has no registers left for it: 12 spilled, 28.2 instead of 27.0 ms):
+        // everything dW2 needs goes through the scratch UNDER dZ1's MFMAs - dZ2 out, its transposed fragments and the
+        // layer-2 bias row sums back, H1 out, its fragments back (80 LDS instructions, five per MFMA group; the LDS runs a
+        // wavefront's instructions in order, so one area serves both operands) - instead of two transposes in the open
+        constexpr bool HIDE = SPLIT && !ACTOR;
+        float tr_a[4][4], tr_b[4][4];
+        float pt0 = 0.0f, pt1 = 0.0f;
+        auto opT = [&](int i) {
+            if (i < 16) scr[(16 * (i >> 2) + 4 * q + (i & 3)) * TS + c] = dz2[i >> 2][i & 3];
+            else if (i < 32) tr_a[(i - 16) >> 2][(i - 16) & 3] = scr[(16 * ((i - 16) >> 2) + c) * TS + 4 * ((i - 16) & 3) + q];
+            else if (i < 48) { if ((i & 1) == 0) pt0 += scr[lane * TS + (i - 32)]; else pt1 += scr[lane * TS + (i - 32)]; }
+            else if (i < 64) scr[(16 * ((i - 48) >> 2) + 4 * q + ((i - 48) & 3)) * TS + c] = h1[(i - 48) >> 2][(i - 48) & 3];
+            else tr_b[(i - 64) >> 2][(i - 64) & 3] = scr[(16 * ((i - 64) >> 2) + c) * TS + 4 * ((i - 64) & 3) + q];
+        };
+        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
         {   // dH1^T = W2^T . dZ2^T, reduction over k = 16u + 4q + r; fragments one reduction index ahead, as above
             const float* wcol2 = lds + L::W2 + (4 * q) * S2 + c;
             float fa[4], fb[4];
@@ -876,9 +893,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur_[t], dz2[s >> 2][s & 3], dz1[t], 0, 0, 0);
+                if constexpr (HIDE) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) opT(5 * s + i);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (HIDE) gb2_l += pt0 + pt1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -887,7 +909,6 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
 
         GBSTAMP(5);
         // ---- weight gradients: reduction over the 16 batch rows of the tile ------------------------------------
-        float tr_a[4][4], tr_b[4][4];
         // rowsum: += sum over the tile's 16 batch rows of feature `lane` (the bias gradient; rows past n_rows hold zeros)
         auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4], float* rowsum) {
 #pragma unroll
@@ -930,25 +951,34 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void gmlp_bwd_kernel(const GA
                     gW3[ot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[s], tr_b[t][s], gW3[ot][t], 0, 0, 0);
         }
         }
-        if constexpr (SPLIT) wait_flag(F_SDONE, kt);   // the scratch still holds the previous tile's dZ1^T until it is read
         GBSTAMP(6);
         // dW2[j2][j1] += sum_b dZ2^T[j2][b] H1^T[j1][b]
-        transpose64(dz2, tr_a, &gb2_l);
-        transpose64(h1, tr_b, nullptr);
+        if constexpr (!HIDE) {
+            transpose64(dz2, tr_a, &gb2_l);
+            transpose64(h1, tr_b, nullptr);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2)
+            for (int t2 = 0; t2 < 4; ++t2) {
 #pragma unroll
                 for (int t1 = 0; t1 < 4; ++t1)
                     gW2[t2][t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_a[t2][s], tr_b[t1][s], gW2[t2][t1], 0, 0, 0);
+                if constexpr (HIDE) {                 // dZ1^T to the scratch under these MFMAs; the gradient wavefront takes it from there
+                    const int i = 4 * s + t2;
+                    scr[(16 * (i >> 2) + 4 * q + (i & 3)) * TS + c] = dz1[i >> 2][i & 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         GBSTAMP(7);
         // dW1[j][i] += sum_b dZ1^T[j][b] X[b][i]
-        if constexpr (SPLIT) {                        // dZ1^T to the scratch; the gradient wavefront takes it from there
+        if constexpr (SPLIT) {
+            if constexpr (!HIDE) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = dz1[t][r];
+                    for (int r = 0; r < 4; ++r) scr[(16 * t + 4 * q + r) * TS + c] = dz1[t][r];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             post_flag(F_READY, kt + 1);
             ++kt;
