@@ -19,6 +19,7 @@
 
 #include "edgemarl.h"
 #include "em_common.h"
+#include "em_lanes.h"
 
 namespace {
 
@@ -172,30 +173,47 @@ __device__ inline void gather_h1(const CCArgs& a, const float* lds, int k, int64
         for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
 }
 
-__device__ inline void head_forward(const float* lds, int q, int c, const f32x4 (&h1)[4], f32x4 (&h2)[4], f32x4& y)
+// Layer 2 on the matrix cores (the fragments of the next reduction index are requested before the MFMAs of this one: the
+// compiler's own schedule waited for LDS after every pair of words), the one-output head on the vector ALU: v = b3 + w3 . h2
+// from the sixteen h2 values the lane holds (four partial sums, two row exchanges), on every lane of the row, instead of a
+// chain of sixteen dependent MFMAs of which 1/16 is used (as the critics of mappo_bwd.hip / gmlp.hip).
+__device__ inline void head_forward(const float* lds, int q, int c, const f32x4 (&h1)[4], f32x4 (&h2)[4], float& y0)
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[t][r] = lds[H_B2 + 16 * t + 4 * q + r];
+    {
+        const float* wrow = lds + H_W2 + c * S2 + 4 * q;
+        float fa[4], fb[4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+        for (int t = 0; t < 4; ++t) fa[t] = wrow[16 * t * S2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[H_W2 + (16 * t + c) * S2 + k], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+        for (int s = 0; s < 16; ++s) {
+            float (&cur_)[4] = (s & 1) ? fb : fa;
+            float (&nxt_)[4] = (s & 1) ? fa : fb;
+            if (s + 1 < 16) {
+                const int k1 = 16 * ((s + 1) >> 2) + ((s + 1) & 3);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) nxt_[t] = wrow[16 * t * S2 + k1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur_[t], h1[s >> 2][s & 3], h2[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    float ps[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + H_W3 + 16 * t + 4 * q);
+        ps[t] = w[0] * h2[t][0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = lds[H_B3 + 4 * q + r];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int k = 16 * (s >> 2) + 4 * q + (s & 3);
-        y = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[H_W3 + c * S2 + k], h2[s >> 2][s & 3], y, 0, 0, 0);
+        for (int r = 1; r < 4; ++r) ps[t] = fmaf(w[r], h2[t][r], ps[t]);
     }
+    y0 = em_rows_sum((ps[0] + ps[1]) + (ps[2] + ps[3])) + lds[H_B3];
 }
 
 __global__ __launch_bounds__(256) void cc_head_fwd_kernel(const CCArgs a)
@@ -222,10 +240,11 @@ __global__ __launch_bounds__(256) void cc_head_fwd_kernel(const CCArgs a)
             const int64_t sn = s + (int64_t)gridDim.x * 64;
             if (sn < a.n_states) { k_n = (int)a.k_arr[sn]; first_n = a.first_arr[sn]; }
         }
-        f32x4 h1[4], h2[4], y;
+        f32x4 h1[4], h2[4];
+        float y0;
         gather_h1(a, lds, k, first, q, h1);
-        head_forward(lds, q, c, h1, h2, y);
-        if (valid && k > 0 && q == 0) a.value_out[s] = y[0] * a.norm_scale + a.norm_mean;   // denormalize, mappo_algorithm.py:384-386
+        head_forward(lds, q, c, h1, h2, y0);
+        if (valid && k > 0 && q == 0) a.value_out[s] = y0 * a.norm_scale + a.norm_mean;   // denormalize, mappo_algorithm.py:384-386
     }
 }
 
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256) void cc_head_fwd_kernel(const CCArgs a)
 constexpr int HS_B1 = 0, HS_W2 = HID, HS_B2 = HS_W2 + HID * HID, HS_W3 = HS_B2 + HID, HS_B3 = HS_W3 + HID, HS_LOSS = HS_B3 + 1,
               HS_STRIDE = HS_LOSS + 3;
 
-__global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
+__global__ __launch_bounds__(256, 2) void cc_head_bwd_kernel(const CCArgs a)
 {
     __shared__ float lds[H_END + 4 * HID * TS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,42 +287,71 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
             const int64_t sn = s + (int64_t)gridDim.x * 64;
             if (sn < a.n_states) { k_n = (int)a.k_arr[sn]; first_n = a.first_arr[sn]; }
         }
-        f32x4 h1[4], h2[4], y;
+        // the returns of the state's first KPRE transitions are requested here, unconditionally, and used after the forward
+        // pass (read inside the loss, each was a dependent memory round trip on the lanes that evaluate it)
+        constexpr int KPRE = 4;
+        float p_ret[KPRE];
+#pragma unroll
+        for (int j = 0; j < KPRE; ++j) p_ret[j] = a.ent_ret[first + (j < k ? j : 0)];
+        f32x4 h1[4], h2[4];
+        float y0;
         gather_h1(a, lds, k, first, q, h1);
-        head_forward(lds, q, c, h1, h2, y);
-        f32x4 dy = zero4;
+        head_forward(lds, q, c, h1, h2, y0);
+        float dy0 = 0.0f;
         if (valid && k > 0 && q == 0) {
             float gsum = 0.0f;
-            for (int j = 0; j < k; ++j) {          // the state's k transitions share its value (mappo_algorithm.py:303,312-314)
-                const float e = (y[0] - a.norm_mean) / a.norm_scale - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
+            const float vn = (y0 - a.norm_mean) / a.norm_scale;
+#pragma unroll
+            for (int j = 0; j < KPRE; ++j) {       // the state's k transitions share its value (mappo_algorithm.py:303,312-314)
+                if (j < k) {
+                    const float e = vn - (p_ret[j] - a.norm_mean) / a.norm_scale;
+                    gsum += e;
+                    loss_sum += (double)(e * e);
+                }
+            }
+            for (int j = KPRE; j < k; ++j) {
+                const float e = vn - (a.ent_ret[first + j] - a.norm_mean) / a.norm_scale;
                 gsum += e;
                 loss_sum += (double)(e * e);
             }
             cnt_sum += (float)k;
-            dy[0] = a.vcoef * a.inv_L * gsum / a.norm_scale;
-            gb3 += dy[0];
+            dy0 = a.vcoef * a.inv_L * gsum / a.norm_scale;
+            gb3 += dy0;
         }
+        // value head on the vector ALU: dH2 = w3 * dv through the ReLU; dW3 accumulates dv * h2 per lane (row c's share, the
+        // sixteen rows' lanes are summed when the slab row is written)
+        const float dv = em_rows_sum(dy0);             // only the lane with q = 0 holds dL/dv of row c, the others 0
         f32x4 dz2[4], dz1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dz2[t] = zero4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[H_W3 + (4 * q + r) * S2 + 16 * t + c], dy[r], dz2[t], 0, 0, 0);
-#pragma unroll
         for (int t = 0; t < 4; ++t) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + H_W3 + 16 * t + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz2[t][r] = h2[t][r] > 0.0f ? dz2[t][r] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                gW3[t][r] = fmaf(dv, h2[t][r], gW3[t][r]);
+                dz2[t][r] = h2[t][r] > 0.0f ? w[r] * dv : 0.0f;
+            }
             dz1[t] = zero4;
             gb2[t] += dz2[t];
         }
+        {   // dH1^T = W2^T . dZ2^T; fragments one reduction index ahead
+            const float* wcol = lds + H_W2 + (4 * q) * S2 + c;
+            float fa[4], fb[4];
 #pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            const int kk = 16 * (sidx >> 2) + 4 * q + (sidx & 3);
+            for (int t = 0; t < 4; ++t) fa[t] = wcol[16 * t];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[H_W2 + kk * S2 + 16 * t + c], dz2[sidx >> 2][sidx & 3], dz1[t], 0, 0, 0);
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                float (&cur_)[4] = (sidx & 1) ? fb : fa;
+                float (&nxt_)[4] = (sidx & 1) ? fa : fb;
+                if (sidx + 1 < 16) {
+                    const int k1 = 16 * ((sidx + 1) >> 2) + ((sidx + 1) & 3);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nxt_[t] = wcol[k1 * S2 + 16 * t];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dz1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur_[t], dz2[sidx >> 2][sidx & 3], dz1[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -317,7 +365,7 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
             for (int t = 0; t < 4; ++t) dst[4 * t + q] = make_float4(dz1[t][0], dz1[t][1], dz1[t][2], dz1[t][3]);
         }
         // weight gradients of layers 3 and 2 (reduction over the tile's 16 states through LDS transposes)
-        float tr_a[4][4], tr_b[4][4], tr_y[4];
+        float tr_a[4][4], tr_b[4][4];
         auto transpose64 = [&](const f32x4(&m)[4], float(&out)[4][4]) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -332,19 +380,6 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
-#pragma unroll
-        for (int r = 0; r < 4; ++r) scr[(4 * q + r) * TS + c] = dy[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int sx = 0; sx < 4; ++sx) tr_y[sx] = scr[c * TS + 4 * sx + q];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        transpose64(h2, tr_b);
-#pragma unroll
-        for (int sx = 0; sx < 4; ++sx)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) gW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr_y[sx], tr_b[t][sx], gW3[t], 0, 0, 0);
         transpose64(dz2, tr_a);
         transpose64(h1, tr_b);
 #pragma unroll
@@ -364,10 +399,15 @@ __global__ __launch_bounds__(256) void cc_head_bwd_kernel(const CCArgs a)
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1) out[HS_W2 + j * HID + 16 * t1 + c] = gW2[t][t1][r];
         }
-    if (q == 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) out[HS_W3 + 16 * t + c] = gW3[t][0];          // output row o = 0
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                  // gW3[t][r]: this lane's (row c) share of dW3[0][16t + 4q + r]
+            float v = gW3[t][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+            if (c == 0) out[HS_W3 + 16 * t + 4 * q + r] = v;
+        }
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1)
 #pragma unroll
@@ -540,7 +580,11 @@ int em_cc_forward(const em_central_critic* net, const float* ent_obs, const int6
     a.norm_mean = value_norm_mean; a.norm_scale = sqrtf(value_norm_var + 1e-8f);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cc_l1_fwd_kernel, dim3((unsigned)(net->n_deciders * split)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(cc_head_fwd_kernel, dim3((unsigned)head_blocks(n_states)), dim3(256), 0, s, a);
+    // 92 registers: four workgroups per CU hide the gather of the partial rows (the backward kernel's slab fixes ITS grid)
+    const int64_t fwd_tiles = (n_states + 15) / 16;
+    int64_t fwd_blocks = (fwd_tiles + 3) / 4;
+    if (fwd_blocks > 1024) fwd_blocks = 1024;
+    hipLaunchKernelGGL(cc_head_fwd_kernel, dim3((unsigned)(fwd_blocks < 1 ? 1 : fwd_blocks)), dim3(256), 0, s, a);
     return em::hip_check(hipGetLastError(), "central critic forward launch");
 }
 
