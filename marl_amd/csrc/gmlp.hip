@@ -338,6 +338,9 @@ __device__ unsigned long long gfwd_stamps[16 * 8];
 // run-time widths every "is this column real" test of the epilogue (3 per element, 20 elements per lane) is a
 // loop-invariant lane mask: the compiler hoisted 200 SGPRs of them out of the tile loop, spilled them into VGPR lanes and
 // paid a v_readlane plus hazard nops for each one in every tile.
+#ifndef EM_GFWD_PIPE
+#define EM_GFWD_PIPE (NW > 4)
+#endif
 template <int KU, int OT, int MODE, int NW = 4, int KC = 0, int OC = 0>
 __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
 {
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
         load_x_frag<KU, KC>(a, grow, valid, q, xb);
         f32x4 h1[4], h2[4], y[OT];
         GSTAMP(3);
-        forward_tile<KU, OT, NoHook, (NW > 4), (MODE == MODE_VALUE && OT == 1)>(lds, xb, q, c, h1, h2, y);
+        forward_tile<KU, OT, NoHook, (NW > 4), (MODE == MODE_VALUE && OT == 1), EM_GFWD_PIPE>(lds, xb, q, c, h1, h2, y);
         GSTAMP(4);
 
         if constexpr (MODE == MODE_PLAIN) {
