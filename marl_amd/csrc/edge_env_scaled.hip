@@ -42,14 +42,20 @@ enum { PCAP = EMS_PENDING_CAP, WAVES_PER_BLOCK = 4, PRE_POIS = 6, CHAIN_ROWS = 1
 enum { SI_STEP = 0, SI_TASKS, SI_VIOL, SI_DONE, SI_PENDING, SI_LOGGED };
 enum { SS_TIME = 0, SS_ELAPSED, SS_SUMLAT, SS_SUMEN };
 
-// state record of one environment (HBM, 16-byte multiple):
+// state record of one environment (HBM, a whole number of 128-byte lines):
 //   f64 load[S] | i32 queue[S] | f64 sim_time, elapsed, sum_lat, sum_energy | i32 step, tasks, viol, completed, pending, logged, 0, 0
-//   | pending list, slot-major arrays: f64 wl[64] | f64 data[64] | f64 deadline[64] | i32 decider[64]
+//   | pending list, 64 entries of 32 bytes in arrival order: {f64 workload, f64 data, f64 deadline, i32 decider, i32 0}
+// A step reads the first k entries (k = 2.2 on average at 64 x 256): as entries they share one or two lines with the
+// scalars in front of them.  (Until round 3 the list was four slot-major arrays - a line of each per step for 63 useful
+// bytes - and records of 2,624 bytes started mid-line every other environment: the HBM counters showed 1.96 x the
+// algorithmic bytes on the read side.)
+struct PendEntry { double wl, data, ddl; int32_t dec, pad; };
+static_assert(sizeof(PendEntry) == 32, "pending entries are 32 bytes");
 __host__ __device__ inline int srec_off_queue(int S) { return 8 * S; }
-__host__ __device__ inline int srec_off_scal(int S) { return (12 * S + 7) & ~7; }
+__host__ __device__ inline int srec_off_scal(int S) { return (12 * S + 31) & ~31; }
 __host__ __device__ inline int srec_off_int(int S) { return srec_off_scal(S) + 32; }
 __host__ __device__ inline int srec_off_pend(int S) { return srec_off_int(S) + 32; }
-__host__ __device__ inline int srec_bytes(int S) { return (srec_off_pend(S) + 28 * PCAP + 15) & ~15; }
+__host__ __device__ inline int srec_bytes(int S) { return (srec_off_pend(S) + 32 * PCAP + 127) & ~127; }
 
 struct ScaledParams {
     int32_t S, D, horizon, rate_mode, explore, rec_bytes, by_slot, step_no;
@@ -181,10 +187,7 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
     int32_t* g_queue = reinterpret_cast<int32_t*>(rec + srec_off_queue(S));
     double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
     int32_t* g_int = reinterpret_cast<int32_t*>(rec + srec_off_int(S));
-    double* g_pwl = reinterpret_cast<double*>(rec + srec_off_pend(S));
-    double* g_pdata = g_pwl + PCAP;
-    double* g_pddl = g_pdata + PCAP;
-    int32_t* g_pdec = reinterpret_cast<int32_t*>(g_pddl + PCAP);
+    PendEntry* g_pend = reinterpret_cast<PendEntry*>(rec + srec_off_pend(S));
     const uint64_t below = lanes_below(lane);
 
     // ---- global loads first ------------------------------------------------------------------------------------
@@ -205,7 +208,8 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
     const bool have = !RESET && lane < k_old;
     if constexpr (!RESET) {
         if (have) {
-            dec = g_pdec[lane]; wl = g_pwl[lane]; data = g_pdata[lane]; ddl = g_pddl[lane];
+            const PendEntry pe = g_pend[lane];
+            dec = pe.dec; wl = pe.wl; data = pe.data; ddl = pe.ddl;
             const int64_t ai = p.by_slot ? env * PCAP + lane : env * (int64_t)D + dec;
             tgt_in = placement[ai];
             res_in = resource[ai];
@@ -389,7 +393,7 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
         }
     }
     if (is_new) {                                           // MRRL.PY:361: the decider's pending task
-        g_pwl[rank] = a_wl; g_pdata[rank] = a_data; g_pddl[rank] = a_deadline; g_pdec[rank] = a_dec;
+        g_pend[rank] = PendEntry{a_wl, a_data, a_deadline, a_dec, 0};
         out.pend_decider[env * PCAP + rank] = a_dec;
     }
 
@@ -426,7 +430,7 @@ __device__ __forceinline__ void step_one_env(const ScaledParams& p, unsigned cha
                     row[c] = v;
                 }
                 if (lane == 0) {
-                    g_pwl[n_pending] = twl; g_pdata[n_pending] = tdata; g_pddl[n_pending] = deadline; g_pdec[n_pending] = tdec;
+                    g_pend[n_pending] = PendEntry{twl, tdata, deadline, tdec, 0};
                     out.pend_decider[env * PCAP + n_pending] = tdec;
                     s_pdec[n_pending] = tdec;
                 }
@@ -554,10 +558,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     unsigned char* rec = state + renv * (int64_t)RB;
     double* g_scal = reinterpret_cast<double*>(rec + srec_off_scal(S));
     int32_t* g_int = reinterpret_cast<int32_t*>(rec + srec_off_int(S));
-    double* g_pwl = reinterpret_cast<double*>(rec + srec_off_pend(S));
-    double* g_pdata = g_pwl + PCAP;
-    double* g_pddl = g_pdata + PCAP;
-    int32_t* g_pdec = reinterpret_cast<int32_t*>(g_pddl + PCAP);
+    PendEntry* g_pend = reinterpret_cast<PendEntry*>(rec + srec_off_pend(S));
+    constexpr int PEND_PRE = 6;      // entries 0..5 lie in the two lines that hold the scalars: requested with them, unconditionally
     const uint32_t below = (1u << sl) - 1u;
 
     // ---- every global load of the step is issued up front, none depends on another's result (the step is bound by
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         t_now = g_scal[SS_TIME]; el_now = g_scal[SS_ELAPSED]; acc_lat = g_scal[SS_SUMLAT]; acc_en = g_scal[SS_SUMEN];
         tasks_before = g_int[SI_TASKS]; n_viol_before = g_int[SI_VIOL]; n_done_before = g_int[SI_DONE];
         k_old = g_int[SI_PENDING];
-        dec = g_pdec[sl]; wl = g_pwl[sl]; data = g_pdata[sl]; ddl = g_pddl[sl];
+        if (sl < PEND_PRE) { const PendEntry pe = g_pend[sl]; dec = pe.dec; wl = pe.wl; data = pe.data; ddl = pe.ddl; }
         if (p.by_slot) { tgt_in = placement[renv * PCAP + sl]; res_in = resource[renv * PCAP + sl]; }
     }
     const double window = chain_win[renv];
@@ -627,6 +629,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
     for (int e = 0; e < EPW4; ++e) { s_load[e][lane] = srv_l[e]; s_queue[e][lane] = srv_q[e]; }
     const bool have = !RESET && fast && sl < k_old;
     if constexpr (!RESET) {
+        if (have && sl >= PEND_PRE) {    // more than six pending deciders (rare): their entries, now that the count is known
+            const PendEntry pe = g_pend[sl];
+            dec = pe.dec; wl = pe.wl; data = pe.data; ddl = pe.ddl;
+        }
         if (!p.by_slot && have) { tgt_in = placement[env * (int64_t)D + dec]; res_in = resource[env * (int64_t)D + dec]; }
         if (!have) { dec = 0; tgt_in = -1; res_in = 1.0f; wl = 1.0; data = 1.0; ddl = 0.0; }
     }
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, EMS_MIN_WAVES4) void scaled_e
         }
     }
     if (is_new) {                                           // MRRL.PY:361: the decider's pending task
-        g_pwl[rank] = a_wl; g_pdata[rank] = a_data; g_pddl[rank] = a_deadline; g_pdec[rank] = a_dec;
+        g_pend[rank] = PendEntry{a_wl, a_data, a_deadline, a_dec, 0};
         out.pend_decider[env * PCAP + rank] = a_dec;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
