@@ -101,10 +101,23 @@ __global__ __launch_bounds__(256) void cc_l1_fwd_kernel(const CCArgs a)
     int32_t e0 = entry_of(tile), e1 = entry_of(tile + stride);
     float xb[KU * 4];
     load_obs_frag(a.ent_obs, W, e0 < 0 ? 0 : e0, e0 >= 0, q, xb);
+    // A tile's partial rows are stored at the START of the next tile, right behind that tile's look-ahead loads: stores count
+    // in the same in-order queue as loads, and stored at the end of their own tile they were the youngest entries when the
+    // next tile waited for its operands - every tile then waited for its predecessor's stores to be acknowledged.
+    f32x4 hp[4];
+    int32_t ep = -1;
+    auto store_rows = [&](int32_t e, const f32x4 (&h)[4]) {
+        if (e >= 0) {
+            float4* dst = reinterpret_cast<float4*>(a.P + (int64_t)e * HID);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[4 * t + q] = make_float4(h[t][0], h[t][1], h[t][2], h[t][3]);   // j = 16t + 4q + r
+        }
+    };
     for (; tile < n_tiles; tile += stride) {
         const int32_t e2 = entry_of(tile + 2 * stride);
         float xn[KU * 4];
         load_obs_frag(a.ent_obs, W, e1 < 0 ? 0 : e1, e1 >= 0, q, xn);
+        store_rows(ep, hp);
         f32x4 h[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -114,15 +127,14 @@ __global__ __launch_bounds__(256) void cc_l1_fwd_kernel(const CCArgs a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1s[(16 * t + c) * S1 + k], xb[s], h[t], 0, 0, 0);
         }
-        if (e0 >= 0) {
-            float4* dst = reinterpret_cast<float4*>(a.P + (int64_t)e0 * HID);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[4 * t + q] = make_float4(h[t][0], h[t][1], h[t][2], h[t][3]);   // j = 16t + 4q + r
-        }
+        for (int t = 0; t < 4; ++t) hp[t] = h[t];
+        ep = e0;
         e0 = e1; e1 = e2;
 #pragma unroll
         for (int s = 0; s < KU * 4; ++s) xb[s] = xn[s];
     }
+    store_rows(ep, hp);
 }
 
 // LDS of the head kernels: W2 [64][S2] | W3 [16][S2] (row 0 used) | b1[64] b2[64] b3[16]
