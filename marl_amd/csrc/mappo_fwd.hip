@@ -102,9 +102,16 @@ __device__ __forceinline__ void policy_epilogue(const FwdArgs& a, const f32x4 y,
     }
 }
 
+#ifdef EM_STAMP_FWDV   // cycles per phase of one wavefront's tile loop in em_value_all (tools/stamp_fwdv.py); compiled out of the library
+__device__ unsigned long long fwdv_stamps[8];
+#define VSTAMP(i) do { if (MODE == 2 && KU == 9 && blockIdx.x == 1 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); if ((i) > 0) fwdv_stamps[i] += n_ - vprev_; else fwdv_stamps[0] += 1; vprev_ = n_; } } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
 template <int KU, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
 {
+    unsigned long long vprev_ = 0; (void)vprev_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
     const int K1 = a.net.in_dim, O = a.net.out_dim;
@@ -217,6 +224,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         const int64_t row = tile * 16 + c;          // row relative to row_base
         const bool valid = row < n_rows;
         f32x4 h1[4], h2[4], y;
+        VSTAMP(0);
+#ifdef EM_STAMP_FWDV
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        VSTAMP(1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) h1[t] = bias1[t];
 #pragma unroll
@@ -227,7 +239,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(h1[t][r], 0.0f);
-        // the x fragment is dead from here on: fetch the next tile's while this one finishes (one wavefront per SIMD)
+        // the x fragment is dead from here on: fetch the next tile's while this one finishes (one wavefront per SIMD).
+        // Stamps (tools/stamp_fwdv.py, em_value_all at 65,536 environments): of a tile's 11.5 k cycles, ISSUING these nine
+        // 16-row gather loads costs 1.6 k and the 64 MFMAs behind them 3.4 k instead of 2.0 k; the wait for the tile's
+        // inputs at the top is 0.5 k.  Nothing hides a gather's issue cost with one wavefront per SIMD.
+        VSTAMP(2);
         int c_env = 0, c_agent = 0;
         if constexpr (MODE == 1) { c_env = n_env; c_agent = n_agent; }
         if (tile + tile_stride < n_tiles) {
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
                 if (r_ < n_rows) { n_env = a.ent_env[row_base + r_]; n_agent = (int)a.ent_agent[row_base + r_]; }
             }
         }
+        VSTAMP(3);
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = bias2[t];
 #pragma unroll
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2[t][r] = fmaxf(h2[t][r], 0.0f);
+        VSTAMP(4);
         y = bias3;
         if constexpr (MODE == 2) {
             // value head (one output) on the vector ALU: v = b3 + w3 . h2 from the sixteen h2 values the lane holds (four
@@ -284,8 +302,17 @@ __global__ __launch_bounds__(256, 1) void mlp3_fwd_kernel(const FwdArgs a)
         } else {
             policy_epilogue(a, y, valid, c_env, c_agent, grow, q, c, O, pls, psd);
         }
+        VSTAMP(5);
     }
 }
+
+#ifdef EM_STAMP_FWDV
+extern "C" int em_debug_fwdv_stamps(unsigned long long* out8, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(fwdv_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(fwdv_stamps), sizeof(unsigned long long) * 8);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // trajectory indexing and compaction (RolloutBuffer.add, MAPPOTrainer._store_transition).
