@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 6
+#define EM_ABI_VERSION 7
 
 typedef enum em_status {
     EM_OK = 0,
@@ -184,9 +184,10 @@ int em_get_kernel_variant(const em_handle *h, int32_t *lanes_per_env, int32_t *w
  * ---------------------------------------------------------------------------------------------- */
 #define EMS_PENDING_CAP 64
 #define EMS_INDEX_CURSOR_STRIDE 32
-/* chunk totals + histogram + flag, rounded up to a 128-byte line, then one line per group cursor */
+/* chunk totals + two histograms + flag, rounded up to a 128-byte line, then two sets of one line per group cursor (the
+ * histograms and cursors alternate by step parity: ems_rollout_index clears the set of step t + 1 while it uses that of t) */
 #define EMS_INDEX_SCRATCH_INTS(n_envs, n_deciders) \
-    (((((n_envs) + 255) / 256 + (n_deciders) + 1 + 31) / 32) * 32 + 32 * (int64_t)(n_deciders))
+    (((((n_envs) + 255) / 256 + 2 * (n_deciders) + 1 + 31) / 32) * 32 + 64 * (int64_t)(n_deciders))
 #define EMS_MAX_DECIDERS 4096
 
 typedef struct ems_handle ems_handle;

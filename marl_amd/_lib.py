@@ -14,7 +14,7 @@ from .config import EmConfig, EmmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class EmTape(C.Structure):

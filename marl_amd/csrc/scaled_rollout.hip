@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "edgemarl.h"
@@ -164,6 +165,100 @@ __global__ __launch_bounds__(256) void scaled_index_place_kernel(const ems_rollo
 }
 
 
+// (2)+(3) in one launch, for n_groups == 1 or up to PLACE2_MAX_GROUPS groups: every wavefront (one per environment) sums the
+// chunk totals in front of its chunk and all of them (64 values at 16,384 environments), and - when its environment has
+// entries - scans the step's group histogram itself (four counts per lane at 256 groups) instead of reading what a
+// single-workgroup launch in between would have written: one launch and one kernel boundary fewer per step (4.0 + 1.7 us of
+// 77 at 16,384 environments).  The histogram and the cursors are double-buffered by step parity: this launch reads the
+// buffers of step t and wavefront 0 clears those of step t + 1, which no launch in flight uses; wavefront 0 also writes the
+// step's counters and group offsets.  Cursors start at zero and are offsets INSIDE the group.
+constexpr int PLACE2_MAX_GROUPS = 256;
+__global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_rollout ro, int t, int n_groups, int n_chunks,
+                                                                  const int32_t* __restrict__ pend_decider,
+                                                                  const float* __restrict__ pend_obs,
+                                                                  const int32_t* __restrict__ chunk_tot,
+                                                                  const int32_t* __restrict__ hist, int32_t* __restrict__ cursor,
+                                                                  int32_t* __restrict__ hist_next, int32_t* __restrict__ cursor_next)
+{
+    __shared__ int32_t goff[4][PLACE2_MAX_GROUPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t B = ro.n_envs, b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;                                   // whole wavefronts leave; nothing below synchronises across wavefronts
+    const int chunk = (int)(b / CHUNK);
+    int32_t pre = 0, all = 0;
+    for (int i = lane; i < n_chunks; i += 64) {
+        const int32_t v = chunk_tot[i];
+        all += v;
+        if (i < chunk) pre += v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d); all += __shfl_xor(all, d); }
+    const int64_t base = ro.counters[t];
+    const int64_t i = (int64_t)t * B + b;
+    const int k = ro.k_tb[i];
+    const int32_t rel = pre + ro.first_tb[i];                               // position of the first entry inside the step
+    const bool overflow = base + all > ro.capacity_entries;
+    const int32_t eff = overflow ? 0 : all;
+    const bool book = b == 0;                             // this wavefront keeps the step's books
+    if (book && lane == 0) {
+        if (overflow) atomicOr(ro.err_flag, 8);
+        ro.counters[t + 1] = base + eff;
+        if (n_groups == 1) { ro.group_off[0] = 0; ro.group_off[1] = eff; }
+        else {
+            ro.group_off[n_groups] = eff;
+            ro.group_off[n_groups + 1] = 0;       // {0, total}: the step as ONE group, for a shared network that runs over
+            ro.group_off[n_groups + 2] = eff;     // the same permutation (any order of the step's entries serves it)
+        }
+    }
+    if (n_groups > 1 && (book || (k > 0 && !overflow))) {
+        // exclusive scan of the histogram: lane l holds groups 4l .. 4l + 3
+        int32_t h[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int g = 4 * lane + j; h[j] = g < n_groups ? hist[g] : 0; sum += h[j]; }
+        int32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        int32_t run = inc - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = 4 * lane + j;
+            goff[wave][g] = run;
+            if (book && g < n_groups) {
+                ro.group_off[g] = overflow ? 0 : run;
+                hist_next[g] = 0;
+                cursor_next[g * CUR_STRIDE] = 0;
+            }
+            run += h[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (overflow) {                                                       // capacity overflow: the step records nothing
+        if (lane == 0) { ro.k_tb[i] = 0; ro.first_tb[i] = (int32_t)base; }
+        return;
+    }
+    const int64_t f = base + rel;
+    if (lane == 0) ro.first_tb[i] = (int32_t)f;
+    if (k == 0) return;
+    const int w = ro.n_servers + 4;
+    const float* src = pend_obs + b * PCAP * (int64_t)w;
+    float* dst = ro.ent_obs + f * w;
+    for (int x = lane; x < k * w; x += 64) dst[x] = src[x];               // k consecutive rows on both sides
+    if (lane < k) {
+        const int dec = pend_decider[b * PCAP + lane];
+        const int pos = n_groups > 1 ? goff[wave][dec] + atomicAdd(&cursor[dec * CUR_STRIDE], 1) : rel + lane;
+        ro.perm[pos] = (int32_t)(f + lane);
+        ro.ent_env[f + lane] = (int32_t)b;
+        ro.ent_agent[f + lane] = dec;
+        ro.ent_dst[f + lane] = (int32_t)(b * PCAP + lane);
+        if (ro.ent_state) ro.ent_state[f + lane] = (int32_t)i;
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Grouping of a whole batch of entries by serving network for the update (the reference has one PPO learner per agent:
 // MRRL.PY:611-638 trains them independently, so a learner's rows must be contiguous and in a reproducible order).  A STABLE
@@ -289,13 +384,32 @@ int ems_rollout_index(const ems_rollout* ro, int32_t t, int32_t n_groups, const 
     if (!ro->index_scratch) return em::fail(EM_ERR_INVALID, "ems_rollout_index: index_scratch is required");
     hipStream_t s = (hipStream_t)stream;
     const int n_chunks = (int)((ro->n_envs + CHUNK - 1) / CHUNK);
-    // scratch: [n_chunks] chunk totals/bases | [n_deciders] histogram (zero between calls) | ok flag | pad to a 128-byte
-    // line | [n_deciders] cursors, CUR_STRIDE ints apart
+    const int D = ro->n_deciders;
+    // scratch (EMS_INDEX_SCRATCH_INTS): [n_chunks] chunk totals/bases | [2][n_deciders] histograms | ok flag | pad to a
+    // 128-byte line | [2][n_deciders] cursors, CUR_STRIDE ints apart.  The second histogram / cursor set serves the two-launch
+    // path (buffers alternate by step parity); the three-launch path uses the first set only.
     int32_t* chunk_tot = ro->index_scratch;
     int32_t* hist = chunk_tot + n_chunks;
-    int32_t* ok_flag = hist + ro->n_deciders;
-    int32_t* cursor = ro->index_scratch + ((n_chunks + ro->n_deciders + 1 + CUR_STRIDE - 1) / CUR_STRIDE) * CUR_STRIDE;
+    int32_t* ok_flag = hist + 2 * D;
+    int32_t* cursor = ro->index_scratch + ((n_chunks + 2 * D + 1 + CUR_STRIDE - 1) / CUR_STRIDE) * CUR_STRIDE;
     const size_t lds = n_groups > 1 ? sizeof(int32_t) * (size_t)n_groups : 0;
+    const char* three = getenv("EMS_INDEX_THREE_LAUNCHES");
+    if ((n_groups == 1 || n_groups <= PLACE2_MAX_GROUPS) && !(three && three[0] == '1')) {
+        const int par = t & 1;
+        if (t == 0 && n_groups > 1) {      // a new episode: whatever the last one left in either set
+            EM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * 2 * (size_t)D, s));
+            EM_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * 2 * (size_t)D * CUR_STRIDE, s));
+        }
+        int32_t* hist_t = hist + par * D;
+        int32_t* cur_t = cursor + (size_t)par * D * CUR_STRIDE;
+        hipLaunchKernelGGL(scaled_index_count_kernel, dim3((unsigned)n_chunks), dim3(CHUNK), lds, s, *ro, t, n_groups, n_pending,
+                           pend_decider, chunk_tot, hist_t);
+        hipLaunchKernelGGL(scaled_index_place2_kernel, dim3((unsigned)((ro->n_envs + 3) / 4)), dim3(256), 0, s, *ro, t, n_groups,
+                           n_chunks, pend_decider, pend_obs, chunk_tot, hist_t, cur_t, hist + (par ^ 1) * D,
+                           cursor + (size_t)(par ^ 1) * D * CUR_STRIDE);
+        return em::hip_check(hipGetLastError(), "scaled rollout index launch");
+    }
+    if (t == 0 && n_groups > 1) EM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)D, s));   // (the other path may have used it)
     hipLaunchKernelGGL(scaled_index_count_kernel, dim3((unsigned)n_chunks), dim3(CHUNK), lds, s, *ro, t, n_groups, n_pending,
                        pend_decider, chunk_tot, hist);
     hipLaunchKernelGGL(scaled_index_scan_kernel, dim3(1), dim3(256), 0, s, *ro, t, n_groups, n_chunks, chunk_tot, hist, cursor, ok_flag);

@@ -57,7 +57,7 @@ class ScaledRolloutStorage:
         if central:        # MAPPO's central critic: state row of every entry and dense per-(step, env) values
             self.t.update(ent_state=z(E, i32), value_tb=z((T, B), f32))
         ptrs = [v.data_ptr() for v in self.t.values()] + ([] if central else [None, None])
-        self.index_scratch = z((((B + 255) // 256 + D + 1 + 31) // 32) * 32 + 32 * D, i32)   # EMS_INDEX_SCRATCH_INTS
+        self.index_scratch = z((((B + 255) // 256 + 2 * D + 1 + 31) // 32) * 32 + 64 * D, i32)   # EMS_INDEX_SCRATCH_INTS
         self.struct = _lib.EmsRollout(B, E, S, D, T, 0, *ptrs, self.index_scratch.data_ptr())
         self.steps_recorded = 0
 

@@ -143,3 +143,39 @@ def test_two_wavefront_grouped_backward_equals_the_one_wavefront_kernel(monkeypa
         (aa, ca, ua), (ab, cb, ub) = outs
         assert np.isfinite(ua["critic_loss"]) and ua == ub, (ua, ub)
         assert torch.equal(aa, ab) and torch.equal(ca, cb)
+
+
+def test_two_launch_index_equals_the_three_launch_path(monkeypatch):
+    """ems_rollout_index with the scan folded into the placement launch (histograms and cursors alternating by step parity)
+    records what the three-launch path records: same counters, entry numbers, group offsets and entry rows, the same SET of
+    entries per group (the order inside a group comes from integer atomics in both), over two episodes in a row (odd
+    horizon: the parity of the last step of an episode equals that of the next one's first) and the same parameters after
+    the updates (the update sorts stably)."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 23
+    outs = []
+    for three in ("0", "1"):
+        monkeypatch.setenv("EMS_INDEX_THREE_LAUNCHES", three)
+        tr = IPPOTrainer(cfg, seed=5, device="cuda:0", n_envs=700, algorithm="ippo", verbose=False)
+        rec = []
+        for _ in range(2):
+            tr.train_episode(explore=True, record_buffer=True)
+            ro = tr.algo.buffer
+            E, tt = ro.total(), ro.t
+            rec.append((E, tt["counters"].clone(), tt["k_tb"].clone(), tt["first_tb"].clone(), tt["ent_obs"][:E].clone(),
+                        tt["ent_agent"][:E].clone(), tt["ent_env"][:E].clone(), tt["group_off"].clone(), tt["perm"].clone()))
+            up = tr.algo.update()
+        outs.append((rec, tr.algo.actor.flat.clone(), tr.algo.critic.flat.clone(), up))
+    (ra, aa, ca, ua), (rb, ab, cb, ub) = outs
+    for x, y in zip(ra, rb):
+        assert x[0] == y[0] and x[0] > 700
+        for u, v in zip(x[1:8], y[1:8]):
+            assert torch.equal(u, v)
+        # the last step's permutation: the same entries in every group
+        off = x[7].tolist()
+        D = tr.algo.D
+        for g in range(D):
+            assert torch.equal(torch.sort(x[8][off[g]:off[g + 1]]).values, torch.sort(y[8][off[g]:off[g + 1]]).values)
+    assert ua == ub and torch.equal(aa, ab) and torch.equal(ca, cb)
