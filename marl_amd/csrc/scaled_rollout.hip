@@ -5,10 +5,12 @@
 // exclusive scan of the per-environment pending counts; (2) the step's entries are grouped by the network that
 // serves them (decider id for independent learners, one group for a shared network) with a counting sort, which gives
 // the group offsets and the position -> entry permutation the grouped MLP kernels (gmlp.hip) consume; (3) the
-// observation rows are copied into the entry storage.  Three short launches: a chunk-parallel count (scan inside
-// 256-environment chunks + histogram), a single-workgroup scan of the chunk totals and of the histogram, and a
-// wavefront-per-environment placement + copy.  The order inside a group comes from integer atomics and may vary from run
-// to run: the rollout forward treats rows independently, so results do not depend on it (the update sorts stably).
+// observation rows are copied into the entry storage.  Two short launches: a chunk-parallel count (scan inside
+// 256-environment chunks + histogram) and a wavefront-per-environment placement + copy in which every wavefront redoes
+// the scan of the chunk totals and of the histogram for itself (scaled_index_place2_kernel); above 256 groups, or with
+// EMS_INDEX_THREE_LAUNCHES=1, a single-workgroup scan launch stands between the two.  The order inside a group comes from
+// integer atomics and may vary from run to run: the rollout forward treats rows independently, so results do not depend
+// on it (the update sorts stably).
 // (A single-workgroup version of (1)+(2) cost 29 us per step at 4,096 environments and 117 us at 16,384.)
 #include <hip/hip_runtime.h>
 
