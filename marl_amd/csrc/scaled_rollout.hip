@@ -43,10 +43,19 @@ __global__ __launch_bounds__(CHUNK) void scaled_index_count_kernel(const ems_rol
         for (int i = tid; i < n_groups; i += CHUNK) lh[i] = 0;
         __syncthreads();
     }
-    int k = b < B ? n_pending[b] : 0;
-    k = k < 0 ? 0 : (k > PCAP ? PCAP : k);
-    if (n_groups > 1)
-        for (int j = 0; j < k; ++j) atomicAdd(&lh[pend_decider[b * PCAP + j]], 1);
+    // the count and the first four deciders of the list are requested together (2.2 entries per environment on average):
+    // one memory round trip instead of two for nearly every environment
+    const int64_t bc = b < B ? b : B - 1;
+    int k = n_pending[bc];
+    const int4 d4 = *reinterpret_cast<const int4*>(pend_decider + bc * PCAP);
+    k = (b < B) ? (k < 0 ? 0 : (k > PCAP ? PCAP : k)) : 0;
+    if (n_groups > 1) {
+        if (k > 0) atomicAdd(&lh[d4.x], 1);
+        if (k > 1) atomicAdd(&lh[d4.y], 1);
+        if (k > 2) atomicAdd(&lh[d4.z], 1);
+        if (k > 3) atomicAdd(&lh[d4.w], 1);
+        for (int j = 4; j < k; ++j) atomicAdd(&lh[pend_decider[b * PCAP + j]], 1);
+    }
     int inc = k;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -167,14 +176,23 @@ __global__ __launch_bounds__(256) void scaled_index_place_kernel(const ems_rollo
 }
 
 
-// (2)+(3) in one launch, for n_groups == 1 or up to PLACE2_MAX_GROUPS groups: every wavefront (one per environment) sums the
-// chunk totals in front of its chunk and all of them (64 values at 16,384 environments), and - when its environment has
-// entries - scans the step's group histogram itself (four counts per lane at 256 groups) instead of reading what a
-// single-workgroup launch in between would have written: one launch and one kernel boundary fewer per step (4.0 + 1.7 us of
-// 77 at 16,384 environments).  The histogram and the cursors are double-buffered by step parity: this launch reads the
-// buffers of step t and wavefront 0 clears those of step t + 1, which no launch in flight uses; wavefront 0 also writes the
-// step's counters and group offsets.  Cursors start at zero and are offsets INSIDE the group.
+// (2)+(3) in one launch, for n_groups == 1 or up to PLACE2_MAX_GROUPS groups: every wavefront (two environments, 32 lanes
+// each: a list holds 2.2 entries on average) sums the chunk totals in front of its chunk and all of them (64 values at
+// 16,384 environments), and - when one of its environments has entries - scans the step's group histogram itself (four
+// counts per lane at 256 groups) instead of reading what a single-workgroup launch in between would have written: one
+// launch and one kernel boundary fewer per step.  The histogram and the cursors are double-buffered by step parity: this
+// launch reads the buffers of step t and the wavefront of environment 0 clears those of step t + 1, which no launch in
+// flight uses; that wavefront also writes the step's counters and group offsets.  Cursors start at zero and are offsets
+// INSIDE the group.
+// Every load of the prologue is issued up front, unconditionally and on addresses that are valid for any list length (a
+// load under `if (k > 0)` waits for k first: four dependent memory round trips per wavefront became two): chunk totals,
+// counters, the environments' counts and offsets, the histogram, the first 32 deciders of each list and the first
+// PRE x 32 floats of its observation rows; longer lists take the loops.  (Copying the rows in 16-byte pieces was SLOWER:
+// 21-24 us instead of 11-14 us per step, whatever the number of lanes per environment.)  What is left of the 11 us is the
+// copy itself: 10 MB read + 10 MB written per step.
 constexpr int PLACE2_MAX_GROUPS = 256;
+constexpr int PLACE2_SUB = 32;                   // lanes per environment (16: 11.5 us, 32: 11.2 us, 64: 13.7 us per step at 16,384 environments)
+constexpr int PLACE2_EPW = 64 / PLACE2_SUB;      // environments per wavefront (divides CHUNK: one chunk per wavefront)
 __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_rollout ro, int t, int n_groups, int n_chunks,
                                                                   const int32_t* __restrict__ pend_decider,
                                                                   const float* __restrict__ pend_obs,
@@ -183,25 +201,41 @@ __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_roll
                                                                   int32_t* __restrict__ hist_next, int32_t* __restrict__ cursor_next)
 {
     __shared__ int32_t goff[4][PLACE2_MAX_GROUPS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t B = ro.n_envs, b = (int64_t)blockIdx.x * 4 + wave;
-    if (b >= B) return;                                   // whole wavefronts leave; nothing below synchronises across wavefronts
-    const int chunk = (int)(b / CHUNK);
-    int32_t pre = 0, all = 0;
-    for (int i = lane; i < n_chunks; i += 64) {
-        const int32_t v = chunk_tot[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / PLACE2_SUB, sl = lane % PLACE2_SUB;
+    const int64_t B = ro.n_envs, b0 = ((int64_t)blockIdx.x * 4 + wave) * PLACE2_EPW, b = b0 + sub;
+    if (b0 >= B) return;                                  // whole wavefronts leave; nothing below synchronises across wavefronts
+    const bool live = b < B;
+    const int64_t bc = live ? b : B - 1;
+    const int chunk = (int)(b0 / CHUNK);
+    constexpr int PRE = 3;
+    const int64_t i = (int64_t)t * B + bc;
+    const int w = ro.n_servers + 4;
+    const float* src = pend_obs + bc * PCAP * (int64_t)w;
+    const int32_t ct0 = lane < n_chunks ? chunk_tot[lane] : 0;
+    const int64_t base = ro.counters[t];
+    const int k = live ? (int)ro.k_tb[i] : 0;
+    const int32_t first = ro.first_tb[i];
+    int32_t h[4] = {0, 0, 0, 0};
+    if (n_groups > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int g = 4 * lane + j; h[j] = hist[g < n_groups ? g : 0]; }
+    }
+    const int dec0 = pend_decider[bc * PCAP + sl];
+    float ob[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) ob[j] = src[sl + PLACE2_SUB * j];       // PRE * 32 <= PCAP * w: inside the environment's rows
+    int32_t pre = chunk > lane ? ct0 : 0, all = ct0;
+    for (int c = lane + 64; c < n_chunks; c += 64) {
+        const int32_t v = chunk_tot[c];
         all += v;
-        if (i < chunk) pre += v;
+        if (c < chunk) pre += v;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d); all += __shfl_xor(all, d); }
-    const int64_t base = ro.counters[t];
-    const int64_t i = (int64_t)t * B + b;
-    const int k = ro.k_tb[i];
-    const int32_t rel = pre + ro.first_tb[i];                               // position of the first entry inside the step
+    const int32_t rel = pre + first;                                        // position of the first entry inside the step
     const bool overflow = base + all > ro.capacity_entries;
     const int32_t eff = overflow ? 0 : all;
-    const bool book = b == 0;                             // this wavefront keeps the step's books
+    const bool book = b0 == 0;                            // this wavefront keeps the step's books
     if (book && lane == 0) {
         if (overflow) atomicOr(ro.err_flag, 8);
         ro.counters[t + 1] = base + eff;
@@ -212,11 +246,11 @@ __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_roll
             ro.group_off[n_groups + 2] = eff;     // the same permutation (any order of the step's entries serves it)
         }
     }
-    if (n_groups > 1 && (book || (k > 0 && !overflow))) {
+    if (n_groups > 1 && (book || (__ballot(k > 0) != 0ull && !overflow))) {
         // exclusive scan of the histogram: lane l holds groups 4l .. 4l + 3
-        int32_t h[4], sum = 0;
+        int32_t sum = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int g = 4 * lane + j; h[j] = g < n_groups ? hist[g] : 0; sum += h[j]; }
+        for (int j = 0; j < 4; ++j) { if (4 * lane + j >= n_groups) h[j] = 0; sum += h[j]; }
         int32_t inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -238,25 +272,28 @@ __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_roll
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (!live) return;
     if (overflow) {                                                       // capacity overflow: the step records nothing
-        if (lane == 0) { ro.k_tb[i] = 0; ro.first_tb[i] = (int32_t)base; }
+        if (sl == 0) { ro.k_tb[i] = 0; ro.first_tb[i] = (int32_t)base; }
         return;
     }
     const int64_t f = base + rel;
-    if (lane == 0) ro.first_tb[i] = (int32_t)f;
+    if (sl == 0) ro.first_tb[i] = (int32_t)f;
     if (k == 0) return;
-    const int w = ro.n_servers + 4;
-    const float* src = pend_obs + b * PCAP * (int64_t)w;
     float* dst = ro.ent_obs + f * w;
-    for (int x = lane; x < k * w; x += 64) dst[x] = src[x];               // k consecutive rows on both sides
-    if (lane < k) {
-        const int dec = pend_decider[b * PCAP + lane];
-        const int pos = n_groups > 1 ? goff[wave][dec] + atomicAdd(&cursor[dec * CUR_STRIDE], 1) : rel + lane;
-        ro.perm[pos] = (int32_t)(f + lane);
-        ro.ent_env[f + lane] = (int32_t)b;
-        ro.ent_agent[f + lane] = dec;
-        ro.ent_dst[f + lane] = (int32_t)(b * PCAP + lane);
-        if (ro.ent_state) ro.ent_state[f + lane] = (int32_t)i;
+    const int np = k * w;                                                 // k consecutive rows on both sides
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+        if (sl + PLACE2_SUB * j < np) dst[sl + PLACE2_SUB * j] = ob[j];
+    for (int x = sl + PLACE2_SUB * PRE; x < np; x += PLACE2_SUB) dst[x] = src[x];
+    for (int slot = sl; slot < k; slot += PLACE2_SUB) {
+        const int dec = slot == sl ? dec0 : pend_decider[b * PCAP + slot];
+        const int pos = n_groups > 1 ? goff[wave][dec] + atomicAdd(&cursor[dec * CUR_STRIDE], 1) : rel + slot;
+        ro.perm[pos] = (int32_t)(f + slot);
+        ro.ent_env[f + slot] = (int32_t)b;
+        ro.ent_agent[f + slot] = dec;
+        ro.ent_dst[f + slot] = (int32_t)(b * PCAP + slot);
+        if (ro.ent_state) ro.ent_state[f + slot] = (int32_t)i;
     }
 }
 
@@ -384,6 +421,7 @@ int ems_rollout_index(const ems_rollout* ro, int32_t t, int32_t n_groups, const 
         !ro->group_off || !ro->perm || !ro->err_flag)
         return em::fail(EM_ERR_INVALID, "ems_rollout_index: storage pointers missing");
     if (!ro->index_scratch) return em::fail(EM_ERR_INVALID, "ems_rollout_index: index_scratch is required");
+    if (reinterpret_cast<uintptr_t>(pend_decider) & 15) return em::fail(EM_ERR_INVALID, "ems_rollout_index: pend_decider must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int n_chunks = (int)((ro->n_envs + CHUNK - 1) / CHUNK);
     const int D = ro->n_deciders;
@@ -406,9 +444,9 @@ int ems_rollout_index(const ems_rollout* ro, int32_t t, int32_t n_groups, const 
         int32_t* cur_t = cursor + (size_t)par * D * CUR_STRIDE;
         hipLaunchKernelGGL(scaled_index_count_kernel, dim3((unsigned)n_chunks), dim3(CHUNK), lds, s, *ro, t, n_groups, n_pending,
                            pend_decider, chunk_tot, hist_t);
-        hipLaunchKernelGGL(scaled_index_place2_kernel, dim3((unsigned)((ro->n_envs + 3) / 4)), dim3(256), 0, s, *ro, t, n_groups,
-                           n_chunks, pend_decider, pend_obs, chunk_tot, hist_t, cur_t, hist + (par ^ 1) * D,
-                           cursor + (size_t)(par ^ 1) * D * CUR_STRIDE);
+        const dim3 grid((unsigned)((ro->n_envs + 4 * PLACE2_EPW - 1) / (4 * PLACE2_EPW)));
+        hipLaunchKernelGGL(scaled_index_place2_kernel, grid, dim3(256), 0, s, *ro, t, n_groups, n_chunks, pend_decider, pend_obs,
+                           chunk_tot, hist_t, cur_t, hist + (par ^ 1) * D, cursor + (size_t)(par ^ 1) * D * CUR_STRIDE);
         return em::hip_check(hipGetLastError(), "scaled rollout index launch");
     }
     if (t == 0 && n_groups > 1) EM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)D, s));   // (the other path may have used it)

@@ -158,7 +158,7 @@ def test_two_launch_index_equals_the_three_launch_path(monkeypatch):
     outs = []
     for three in ("0", "1"):
         monkeypatch.setenv("EMS_INDEX_THREE_LAUNCHES", three)
-        tr = IPPOTrainer(cfg, seed=5, device="cuda:0", n_envs=700, algorithm="ippo", verbose=False)
+        tr = IPPOTrainer(cfg, seed=5, device="cuda:0", n_envs=701, algorithm="ippo", verbose=False)
         rec = []
         for _ in range(2):
             tr.train_episode(explore=True, record_buffer=True)
