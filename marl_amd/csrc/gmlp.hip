@@ -355,17 +355,35 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
     const int64_t n_rows = r1 - r0, n_tiles = (n_rows + 15) >> 4;
     if ((int64_t)part * NW >= n_tiles) return;         // uniform over the workgroup: safe before the barrier
     float* sd_t = lds + L::END;
+    // A tile's row numbers - the entries of its rows and, for the policy epilogue, their environment, agent and action slot -
+    // are fetched by one chain of loads on addresses that are valid for any row (entry 0 for rows past the end).  The first
+    // tile's chain is started BEFORE the weights are staged, so that its two dependent memory round trips run beside the
+    // staging instead of behind the barrier (a wavefront has one tile per step in the rollout).
+    int64_t grow = 0;
+    bool valid = false;
+    float xb[KU * 4];
+    int p_env = 0, p_agent = 0, p_dst = 0;
+    auto fetch = [&](int64_t tile_) {
+        const int64_t row_ = tile_ * 16 + c;
+        valid = tile_ < n_tiles && row_ < n_rows;
+        const int64_t at_ = r0 + (valid ? row_ : 0);
+        grow = a.perm ? (int64_t)a.perm[at_] : at_;
+        if (!valid) grow = 0;
+        if constexpr (MODE == MODE_POLICY) {
+            p_env = a.ent_env[grow];
+            p_agent = a.ent_agent[grow];
+            p_dst = a.ent_dst[grow];
+        }
+    };
+    const int64_t tile_stride = (int64_t)a.split * NW;
+    fetch((int64_t)part * NW + wave);
     stage_weights<KU, OT, 64 * NW, (NW > 4)>(lds, a.net, MODE == MODE_POLICY ? a.log_std : nullptr, g, MODE == MODE_POLICY ? sd_t : nullptr, KC, OC);
     GSTAMP(1);
     __syncthreads();
 
-    for (int64_t tile = (int64_t)part * NW + wave; tile < n_tiles; tile += (int64_t)a.split * NW) {
+    for (int64_t tile = (int64_t)part * NW + wave; tile < n_tiles; tile += tile_stride) {
         GSTAMP(2);
-        const int64_t row = tile * 16 + c;
-        const bool valid = row < n_rows;
-        const int64_t grow = valid ? (a.perm ? (int64_t)a.perm[r0 + row] : r0 + row) : 0;
-        float xb[KU * 4];
-        load_x_frag<KU, KC>(a, grow, valid, q, xb);
+        load_x_frag<KU, KC>(a, grow, valid, q, xb);     // (the fragment itself fetched before the staging: 10 spilled registers)
         f32x4 h1[4], h2[4], y[OT];
         GSTAMP(3);
         forward_tile<KU, OT, NoHook, (NW > 4), (MODE == MODE_VALUE && OT == 1), EM_GFWD_PIPE>(lds, xb, q, c, h1, h2, y);
@@ -385,8 +403,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
             // ---- policy epilogue: rsample + log-prob (mappo_algorithm.py:62-71,209-213), action formatting
             //      (mappo_trainer.py:125-158) --------------------------------------------------------------
             const int n = OC ? OC - 1 : a.n_place;
-            const int env = valid ? a.ent_env[grow] : 0;
-            const int agent = valid ? a.ent_agent[grow] : 0;
+            const int env = valid ? p_env : 0;
+            const int agent = valid ? p_agent : 0;
             float lp = 0.0f, best = -__builtin_inff(), res_raw = 0.0f;
             int best_i = 1 << 20;
             bool all_zero = true;
@@ -434,12 +452,13 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
             if (valid && q == 0) {
                 a.ent_logp[grow] = a.explore ? lp : 0.0f;                  // eval: log_prob = 0 (mappo_algorithm.py:218)
                 const int place = all_zero ? 0 : best_i % n;
-                const int64_t dst = a.ent_dst[grow];
+                const int64_t dst = p_dst;
                 a.placement[dst] = place;
                 a.resource[dst] = em_resource_share(res_raw);             // mappo_trainer.py:148-152
             }
             GSTAMP(5);
         }
+        if (tile + tile_stride < n_tiles) fetch(tile + tile_stride);
     }
     GSTAMP(6);
 }
