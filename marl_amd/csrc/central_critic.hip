@@ -549,12 +549,32 @@ __global__ __launch_bounds__(256) void cc_reduce_w1_kernel(const float* __restri
 __global__ __launch_bounds__(256) void cc_reduce_head_kernel(const float* __restrict__ slab, int n_rows, float* __restrict__ grad_tail,
                                                              float* __restrict__ loss3)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HS_STRIDE) return;
+    // 32 columns x 8 row lanes per workgroup: row lane j sums the rows r = j (mod 8) in ascending order, the eight partial
+    // sums are combined in the order j = 0..7 - a fixed order, and 135 workgroups instead of the 17 that summed 2,048 rows
+    // one after the other (0.64 ms per epoch)
+    __shared__ float part[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + cl;
     float acc = 0.0f;
-    for (int r = 0; r < n_rows; ++r) acc += slab[(int64_t)r * HS_STRIDE + p];
-    if (p < HS_LOSS) grad_tail[p] = acc;
-    else loss3[p - HS_LOSS] = acc;
+    if (p < HS_STRIDE) {
+        const float* s = slab + p;
+        int r = rl;
+        for (; r + 24 < n_rows; r += 32) {
+            const float v0 = s[(int64_t)r * HS_STRIDE], v1 = s[(int64_t)(r + 8) * HS_STRIDE], v2 = s[(int64_t)(r + 16) * HS_STRIDE],
+                        v3 = s[(int64_t)(r + 24) * HS_STRIDE];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; r < n_rows; r += 8) acc += s[(int64_t)r * HS_STRIDE];
+    }
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && p < HS_STRIDE) {
+        float t = part[0][cl];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += part[j][cl];
+        if (p < HS_LOSS) grad_tail[p] = t;
+        else loss3[p - HS_LOSS] = t;
+    }
 }
 
 int check_cc(const em_central_critic* n)
@@ -632,7 +652,7 @@ int em_cc_grad(const em_central_critic* net, const float* ent_obs, const int32_t
     a.slab_stride = HS_STRIDE;
     hipLaunchKernelGGL(cc_head_bwd_kernel, dim3((unsigned)hb), dim3(256), 0, s, a);
     float* tail = grad_out + (int64_t)HID * net->ldw;          // [b1 | w2 | b2 | w3 | b3] follow w1
-    hipLaunchKernelGGL(cc_reduce_head_kernel, dim3((HS_STRIDE + 255) / 256), dim3(256), 0, s, slab, hb * 4, tail, loss3_out);
+    hipLaunchKernelGGL(cc_reduce_head_kernel, dim3((HS_STRIDE + 31) / 32), dim3(256), 0, s, slab, hb * 4, tail, loss3_out);
     a.slab_stride = (int64_t)HID * W;
     hipLaunchKernelGGL(cc_l1_bwd_kernel, dim3((unsigned)(D * split)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(cc_reduce_w1_kernel, dim3((unsigned)((HID * W + 255) / 256), (unsigned)D), dim3(256), 0, s, slab, split * 4, W,

@@ -1130,6 +1130,49 @@ __global__ __launch_bounds__(256) void reduce_group_slabs_kernel(const float* __
     else loss3[(int64_t)g * 3 + (p - np)] = acc;
 }
 
+// The same sums for FEW groups with MANY slab rows (a shared network: one group, 1,024 rows of 12.8 k floats): 32 columns x 8
+// row lanes per workgroup - row lane j sums the rows r = j (mod 8) in ascending order, the partial sums are combined in the
+// order j = 0..7 - so that 400 workgroups share the rows instead of 50 (0.25 ms per epoch).
+__global__ __launch_bounds__(256) void reduce_group_slabs_tall_kernel(const float* __restrict__ slab, int rows_per_group, int64_t stride,
+                                                                      float* __restrict__ grads, float* __restrict__ loss3)
+{
+    __shared__ float part[8][32];
+    const int g = blockIdx.y, cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int64_t p = (int64_t)blockIdx.x * 32 + cl;
+    float acc = 0.0f;
+    if (p < stride) {
+        const float* s = slab + (int64_t)g * rows_per_group * stride + p;
+        int r = rl;
+        for (; r + 24 < rows_per_group; r += 32) {
+            const float v0 = s[(int64_t)r * stride], v1 = s[(int64_t)(r + 8) * stride], v2 = s[(int64_t)(r + 16) * stride],
+                        v3 = s[(int64_t)(r + 24) * stride];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; r < rows_per_group; r += 8) acc += s[(int64_t)r * stride];
+    }
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && p < stride) {
+        float t = part[0][cl];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += part[j][cl];
+        const int64_t np = stride - 3;
+        if (p < np) grads[(int64_t)g * np + p] = t;
+        else loss3[(int64_t)g * 3 + (p - np)] = t;
+    }
+}
+
+void reduce_group_slabs(const float* slab, int rows_per_group, int64_t stride, int n_groups, float* grads, float* loss3, hipStream_t s)
+{
+    if (rows_per_group >= 64 && (int64_t)n_groups * ((stride + 255) / 256) < 256) {
+        const dim3 grid((unsigned)((stride + 31) / 32), (unsigned)n_groups);
+        hipLaunchKernelGGL(reduce_group_slabs_tall_kernel, grid, dim3(256), 0, s, slab, rows_per_group, stride, grads, loss3);
+    } else {
+        const dim3 grid((unsigned)((stride + 255) / 256), (unsigned)n_groups);
+        hipLaunchKernelGGL(reduce_group_slabs_kernel, grid, dim3(256), 0, s, slab, rows_per_group, stride, grads, loss3);
+    }
+}
+
 // clip_grad_norm_ (mappo_algorithm.py:328-329) + torch.optim.Adam (:331-332), one workgroup per parameter group
 struct GroupAdam {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
@@ -1491,8 +1534,7 @@ int em_gmlp_actor_grad(const em_gmlp* actor, const float* log_std, const float* 
     hipStream_t s = (hipStream_t)stream;
     rc = launch_gbwd<true>(ga, s);
     if (rc) return rc;
-    const dim3 grid((unsigned)((ga.slab_stride + 255) / 256), (unsigned)actor->n_groups);
-    hipLaunchKernelGGL(reduce_group_slabs_kernel, grid, dim3(256), 0, s, slab, split * 4, ga.slab_stride, grad_out, loss3_out);
+    reduce_group_slabs(slab, split * 4, ga.slab_stride, actor->n_groups, grad_out, loss3_out, s);
     return em::hip_check(hipGetLastError(), "gmlp actor grad launch");
 }
 
@@ -1515,8 +1557,7 @@ int em_gmlp_critic_grad(const em_gmlp* critic, const float* x, int64_t ldx, cons
     hipStream_t s = (hipStream_t)stream;
     rc = launch_gbwd<false>(ga, s);
     if (rc) return rc;
-    const dim3 grid((unsigned)((ga.slab_stride + 255) / 256), (unsigned)critic->n_groups);
-    hipLaunchKernelGGL(reduce_group_slabs_kernel, grid, dim3(256), 0, s, slab, split * 4, ga.slab_stride, grad_out, loss3_out);
+    reduce_group_slabs(slab, split * 4, ga.slab_stride, critic->n_groups, grad_out, loss3_out, s);
     return em::hip_check(hipGetLastError(), "gmlp critic grad launch");
 }
 

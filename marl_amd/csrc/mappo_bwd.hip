@@ -976,8 +976,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, (KU <= 1 ? 2 : 1)) void mlp3_bwd
 // rows rg, rg + 8, ... into four interleaved partial sums each, and thread column p adds the 8 group sums in order.
 // (One thread per column walking every row alone took 340 us for the critic's 13,249 columns x 1,024 rows.)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int64_t n_rows, int64_t stride,
-                                                           int64_t n_cols, float* __restrict__ out)
+                                                           int64_t n_cols, float* __restrict__ out, int64_t n_main,
+                                                           float* __restrict__ out_tail)
 {
+    // columns [0, n_main) go to out, the columns behind them (the three loss sums) to out_tail: one launch for both
     __shared__ float part[8][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int64_t p = (int64_t)blockIdx.x * 32 + col;
@@ -999,7 +1001,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         float s = part[0][col];
 #pragma unroll
         for (int g = 1; g < 8; ++g) s += part[g][col];
-        out[p] = s;
+        if (p < n_main) out[p] = s;
+        else out_tail[p - n_main] = s;
     }
 }
 
@@ -1178,8 +1181,8 @@ int em_ppo_actor_grad(const em_mlp3* actor, const float* log_std, const float* e
     rc = launch_bwd<true>(ba, n_waves, s);
     if (rc) return rc;
     const int64_t np = ba.slab_stride - 3;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 3 + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np + 3, grad_out,
+                       np, loss3_out);
     return em::hip_check(hipGetLastError(), "actor grad launch");
 }
 
@@ -1213,8 +1216,8 @@ int em_ppo_critic_grad_rows(const em_mlp3* critic, const float* state_base, cons
     rc = launch_bwd<false>(ba, n_waves, s);
     if (rc) return rc;
     const int64_t np = ba.slab_stride - 3;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np, grad_out);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, slab + np, n_waves, ba.slab_stride, (int64_t)3, loss3_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((np + 3 + 31) / 32)), dim3(256), 0, s, slab, n_waves, ba.slab_stride, np + 3, grad_out,
+                       np, loss3_out);
     return em::hip_check(hipGetLastError(), "critic grad launch");
 }
 
