@@ -1190,10 +1190,25 @@ __global__ __launch_bounds__(256) void group_adam_kernel(const GroupAdam a, int 
     __shared__ double red[256];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = threadIdx.x;
-    for (; i + 768 < a.n_per_group; i += 1024) {
-        const double g0 = (double)a.grad[base + i], g1 = (double)a.grad[base + i + 256], g2 = (double)a.grad[base + i + 512],
-                     g3 = (double)a.grad[base + i + 768];
-        s0 += g0 * g0; s1 += g1 * g1; s2 += g2 * g2; s3 += g3 * g3;
+    if ((reinterpret_cast<uintptr_t>(a.grad + base) & 15) == 0) {
+        // 16-byte pieces, four of them in flight per thread: every workgroup of a group walks the WHOLE gradient (the 1.1 M
+        // parameters of the central critic: 1,104 dependent batches of four 4-byte loads took 0.34 ms per step)
+        const float4* g4 = reinterpret_cast<const float4*>(a.grad + base);
+        const int64_t n4 = a.n_per_group >> 2;
+        auto sq = [](const float4 v) { return ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w); };
+        int64_t j = threadIdx.x;
+        for (; j + 768 < n4; j += 1024) {
+            const float4 v0 = g4[j], v1 = g4[j + 256], v2 = g4[j + 512], v3 = g4[j + 768];
+            s0 += sq(v0); s1 += sq(v1); s2 += sq(v2); s3 += sq(v3);
+        }
+        for (; j < n4; j += 256) s0 += sq(g4[j]);
+        i = 4 * n4 + threadIdx.x;
+    } else {
+        for (; i + 768 < a.n_per_group; i += 1024) {
+            const double g0 = (double)a.grad[base + i], g1 = (double)a.grad[base + i + 256], g2 = (double)a.grad[base + i + 512],
+                         g3 = (double)a.grad[base + i + 768];
+            s0 += g0 * g0; s1 += g1 * g1; s2 += g2 * g2; s3 += g3 * g3;
+        }
     }
     for (; i < a.n_per_group; i += 256) s0 += (double)a.grad[base + i] * (double)a.grad[base + i];
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
