@@ -257,7 +257,9 @@ typedef struct ems_rollout {
 
 /* Records which deciders act at step t (the pending lists ems_reset/ems_step returned): numbers the entries, copies
  * their observation rows, and groups the step's entries by serving network (n_groups = n_deciders: one network per
- * decider; 1: a shared network) for the grouped MLP kernels below. */
+ * decider; 1: a shared network) for the grouped MLP kernels below.  Steps are indexed in order (t = 0, 1, ...: step t
+ * reads counters[t] and writes counters[t + 1]); pend_decider must be 16-byte aligned (EM_ERR_INVALID otherwise).  Two
+ * launches per call; EMS_INDEX_THREE_LAUNCHES=1 in the environment selects the older three-launch path (same records). */
 int ems_rollout_index(const ems_rollout *ro, int32_t t, int32_t n_groups, const int32_t *n_pending,
                       const int32_t *pend_decider, const float *pend_obs, void *stream);
 
