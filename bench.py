@@ -383,6 +383,7 @@ def time_env_steps(device, rank, world, B, steps, warmup):
     t0 = time.perf_counter()
     ev0.record(stream)
     run(steps, counter)
+    t_sub = time.perf_counter()
     ev1.record(stream)
     # Each rank's clock stops when ITS work is done; the barrier that follows orders the ranks, and the MAX over ranks
     # below is the job's time (the driver times as few as 20 steps, 140 us of GPU work: a barrier inside the clock would
@@ -394,6 +395,9 @@ def time_env_steps(device, rank, world, B, steps, warmup):
         dist.barrier()
     torch.cuda.synchronize(device)
     dev_ms = ev0.elapsed_time(ev1)
+    if rank == 0:      # diagnostic: how long the host took to queue the timed launches (the GPU starves if this exceeds its own time)
+        print(f"[bench] {B} envs: host queued {steps} launches in {(t_sub - t0) * 1e6:.1f} us, GPU {dev_ms * 1e3:.1f} us between the events, "
+              f"wall {elapsed * 1e6:.1f} us", file=sys.stderr, flush=True)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -493,6 +497,7 @@ def scaled_leg(device, rank, world, B=65536, steps=300):
     t0 = time.perf_counter()
     ev0.record(stream)
     run(steps, counter)
+    t_sub = time.perf_counter()
     ev1.record(stream)
     torch.cuda.synchronize(device)
     if world > 1:
