@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define EM_MAX_NODES 64
-#define EM_ABI_VERSION 7
+#define EM_ABI_VERSION 8
 
 typedef enum em_status {
     EM_OK = 0,
@@ -259,7 +259,9 @@ typedef struct ems_rollout {
  * their observation rows, and groups the step's entries by serving network (n_groups = n_deciders: one network per
  * decider; 1: a shared network) for the grouped MLP kernels below.  Steps are indexed in order (t = 0, 1, ...: step t
  * reads counters[t] and writes counters[t + 1]); pend_decider must be 16-byte aligned (EM_ERR_INVALID otherwise).  Two
- * launches per call; EMS_INDEX_THREE_LAUNCHES=1 in the environment selects the older three-launch path (same records). */
+ * launches per call; EMS_INDEX_THREE_LAUNCHES=1 in the environment selects the older three-launch path (same records).
+ * pend_obs NULL: the observation rows are NOT copied here (the caller's em_gmlp_policy_gather launch of the step copies
+ * them while it reads them). */
 int ems_rollout_index(const ems_rollout *ro, int32_t t, int32_t n_groups, const int32_t *n_pending,
                       const int32_t *pend_decider, const float *pend_obs, void *stream);
 
@@ -467,6 +469,15 @@ int em_gmlp_policy(const em_gmlp *actor, const float *log_std, const float *x, i
                    uint64_t seed, uint32_t episode, uint32_t rng_step, uint64_t env_offset, const int32_t *ent_env,
                    const int32_t *ent_agent, const int32_t *ent_dst, int32_t n_place, float *ent_action, float *ent_logp,
                    int32_t *placement, float *resource, void *stream);
+/* em_gmlp_policy for rows whose observations still lie in the environment's pending lists (ems_step_out.pend_obs viewed as
+ * [n_envs * EMS_PENDING_CAP][ldx]): row r reads x_src[ent_dst[r]] and stores it to x_copy[r] ([rows][ldx], the entry storage
+ * ems_rollout.ent_obs) on its way - the observation copy of RolloutBuffer.add (mappo_algorithm.py:104-111) that
+ * ems_rollout_index leaves out when its pend_obs argument is NULL.  Everything else as em_gmlp_policy. */
+int em_gmlp_policy_gather(const em_gmlp *actor, const float *log_std, const float *x_src, float *x_copy, int64_t ldx,
+                          int64_t n_rows, const int64_t *group_off, const int32_t *perm, int32_t split, const float *noise,
+                          int explore, uint64_t seed, uint32_t episode, uint32_t rng_step, uint64_t env_offset,
+                          const int32_t *ent_env, const int32_t *ent_agent, const int32_t *ent_dst, int32_t n_place,
+                          float *ent_action, float *ent_logp, int32_t *placement, float *resource, void *stream);
 /* MAPPO.get_values per row (mappo_algorithm.py:226-239): value[row] = critic_g(x[row]) de-normalised. */
 int em_gmlp_value(const em_gmlp *critic, const float *x, int64_t ldx, int64_t n_rows, const int64_t *group_off,
                   const int32_t *perm, int32_t split, float value_norm_mean, float value_norm_var, float *value,

@@ -14,7 +14,7 @@ from .config import EmConfig, EmmConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libedgemarl.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class EmTape(C.Structure):
@@ -182,6 +182,8 @@ def lib() -> C.CDLL:
     L.em_gmlp_forward.argtypes = [G, vp, i64, i64, vp, vp, C.c_int32, vp, vp]
     L.em_gmlp_policy.argtypes = [G, vp, vp, i64, i64, vp, vp, C.c_int32, vp, i32, u64, C.c_uint32, C.c_uint32, u64,
                                  vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.em_gmlp_policy_gather.argtypes = [G, vp, vp, vp, i64, i64, vp, vp, C.c_int32, vp, i32, u64, C.c_uint32, C.c_uint32, u64,
+                                        vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
     L.em_gmlp_value.argtypes = [G, vp, i64, i64, vp, vp, C.c_int32, f32, f32, vp, vp]
     L.em_gmlp_slab_floats.argtypes = [C.c_int32, C.c_int32, i32]
     L.em_gmlp_slab_floats.restype = i64
@@ -197,7 +199,7 @@ def lib() -> C.CDLL:
     L.em_cc_grad.argtypes = [CC, vp, vp, vp, vp, vp, C.c_int32, vp, i64, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
     L.em_cc_forward.restype = C.c_int
     L.em_cc_grad.restype = C.c_int
-    for name in ("em_gmlp_forward", "em_gmlp_policy", "em_gmlp_value", "em_gmlp_actor_grad", "em_gmlp_critic_grad",
+    for name in ("em_gmlp_forward", "em_gmlp_policy", "em_gmlp_policy_gather", "em_gmlp_value", "em_gmlp_actor_grad", "em_gmlp_critic_grad",
                  "em_group_adam", "em_group_moments", "em_gae_agents"):
         getattr(L, name).restype = C.c_int
     for name in ("em_mlp3_forward", "em_rollout_index", "em_policy_step", "em_gae", "em_ppo_actor_grad",

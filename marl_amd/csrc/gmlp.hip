@@ -61,6 +61,8 @@ struct GArgs {
     uint32_t seed_lo, seed_hi, episode, step, env_offset, pad1;
     float* value;              // MODE_VALUE: [rows]
     float norm_mean, norm_scale;
+    float* x_copy;             // MODE_POLICY, optional: x is read at row ent_dst[row] (the environment's pending lists) and the
+                               // row is stored here at [row][ldx] on its way (the entry storage's observation copy)
     // backward
     float* slab;               // [n_groups][split * 4][slab_stride]
     int64_t slab_stride;
@@ -326,6 +328,26 @@ __device__ inline void load_x_frag(const GArgs& a, int64_t grow, bool valid, int
     }
 }
 
+// the x fragment back to memory: row grow of a.x_copy (em_gmlp_policy_gather)
+template <int KU, int KC = 0>
+__device__ inline void store_x_frag(const GArgs& a, int64_t grow, int q, const float (&xb)[KU * 4])
+{
+    const int K1 = KC ? KC : a.net.in_dim;
+    const bool vec_ok = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x_copy) & 15) == 0);
+    float* xr = a.x_copy + grow * a.ldx;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int k = 16 * u + 4 * q;
+        if (vec_ok && k + 3 < K1) {
+            *reinterpret_cast<float4*>(xr + k) = make_float4(xb[u * 4 + 0], xb[u * 4 + 1], xb[u * 4 + 2], xb[u * 4 + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k + r < K1) xr[k + r] = xb[u * 4 + r];
+        }
+    }
+}
+
 // NW wavefronts per workgroup (16 by default: 95 vs 101 ms per IPPO rollout with 8, 112 with 4): a group's tiles (about nine per learner and step in the IPPO rollout) are dealt to more
 // wavefronts, two per SIMD, so that one's epilogue arithmetic runs under the other's MFMAs
 #ifdef EM_STAMP_GFWD   // cycle stamps of every wavefront of one workgroup (tools/stamp_gfwd.py)
@@ -383,7 +405,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
 
     for (int64_t tile = (int64_t)part * NW + wave; tile < n_tiles; tile += tile_stride) {
         GSTAMP(2);
-        load_x_frag<KU, KC>(a, grow, valid, q, xb);     // (the fragment itself fetched before the staging: 10 spilled registers)
+        // (the fragment itself fetched before the staging: 10 spilled registers)
+        if constexpr (MODE == MODE_POLICY) {
+            const bool gather = a.x_copy != nullptr;     // rows still in the environment's pending lists: read there, copy here
+            load_x_frag<KU, KC>(a, gather ? (int64_t)p_dst : grow, valid, q, xb);
+            if (gather && valid) store_x_frag<KU, KC>(a, grow, q, xb);
+        } else {
+            load_x_frag<KU, KC>(a, grow, valid, q, xb);
+        }
         f32x4 h1[4], h2[4], y[OT];
         GSTAMP(3);
         forward_tile<KU, OT, NoHook, (NW > 4), (MODE == MODE_VALUE && OT == 1), EM_GFWD_PIPE>(lds, xb, q, c, h1, h2, y);
@@ -1502,6 +1531,31 @@ int em_gmlp_policy(const em_gmlp* actor, const float* log_std, const float* x, i
     if (n_rows == 0) return EM_OK;
     GArgs ga;
     fill_common(ga, actor, x, ldx, n_rows, group_off, perm, split);
+    ga.log_std = log_std; ga.noise = noise; ga.ent_action = ent_action; ga.ent_logp = ent_logp; ga.ent_env = ent_env;
+    ga.ent_agent = ent_agent; ga.ent_dst = ent_dst; ga.placement = placement; ga.resource = resource; ga.n_place = n_place;
+    ga.explore = explore ? 1 : 0;
+    ga.seed_lo = (uint32_t)seed; ga.seed_hi = (uint32_t)(seed >> 32); ga.episode = episode; ga.step = rng_step;
+    ga.env_offset = (uint32_t)env_offset;
+    return launch_gfwd<MODE_POLICY>(ga, (hipStream_t)stream);
+}
+
+int em_gmlp_policy_gather(const em_gmlp* actor, const float* log_std, const float* x_src, float* x_copy, int64_t ldx, int64_t n_rows,
+                          const int64_t* group_off, const int32_t* perm, int32_t split, const float* noise, int explore,
+                          uint64_t seed, uint32_t episode, uint32_t rng_step, uint64_t env_offset, const int32_t* ent_env,
+                          const int32_t* ent_agent, const int32_t* ent_dst, int32_t n_place, float* ent_action, float* ent_logp,
+                          int32_t* placement, float* resource, void* stream)
+{
+    int rc = check_gnet(actor);
+    if (rc) return rc;
+    rc = check_rows(actor, x_src, ldx, n_rows, group_off, split);
+    if (rc) return rc;
+    if (!x_copy || !log_std || !ent_env || !ent_agent || !ent_dst || !ent_action || !ent_logp || !placement || !resource)
+        return em::fail(EM_ERR_INVALID, "em_gmlp_policy_gather: null argument");
+    if (n_place < 1 || n_place + 1 != actor->out_dim) return em::fail(EM_ERR_INVALID, "em_gmlp_policy_gather: out_dim must be n_place + 1");
+    if (n_rows == 0) return EM_OK;
+    GArgs ga;
+    fill_common(ga, actor, x_src, ldx, n_rows, group_off, perm, split);
+    ga.x_copy = x_copy;
     ga.log_std = log_std; ga.noise = noise; ga.ent_action = ent_action; ga.ent_logp = ent_logp; ga.ent_env = ent_env;
     ga.ent_agent = ent_agent; ga.ent_dst = ent_dst; ga.placement = placement; ga.resource = resource; ga.n_place = n_place;
     ga.explore = explore ? 1 : 0;

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void scaled_index_place_kernel(const ems_rollo
     const int w = ro.n_servers + 4;
     const float* src = pend_obs + b * PCAP * (int64_t)w;
     float* dst = ro.ent_obs + f * w;
-    for (int x = lane; x < k * w; x += 64) dst[x] = src[x];               // k consecutive rows on both sides
+    if (pend_obs)
+        for (int x = lane; x < k * w; x += 64) dst[x] = src[x];           // k consecutive rows on both sides
     if (lane < k) {
         const int dec = pend_decider[b * PCAP + lane];
         const int pos = n_groups > 1 ? atomicAdd(&cursor[dec * CUR_STRIDE], 1) : rel + lane;
@@ -221,9 +222,12 @@ __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_roll
         for (int j = 0; j < 4; ++j) { const int g = 4 * lane + j; h[j] = hist[g < n_groups ? g : 0]; }
     }
     const int dec0 = pend_decider[bc * PCAP + sl];
-    float ob[PRE];
+    const bool copy = pend_obs != nullptr;                // NULL: the caller's policy launch copies the rows (em_gmlp_policy_gather)
+    float ob[PRE] = {};
+    if (copy) {
 #pragma unroll
-    for (int j = 0; j < PRE; ++j) ob[j] = src[sl + PLACE2_SUB * j];       // PRE * 32 <= PCAP * w: inside the environment's rows
+        for (int j = 0; j < PRE; ++j) ob[j] = src[sl + PLACE2_SUB * j];   // PRE * 32 <= PCAP * w: inside the environment's rows
+    }
     int32_t pre = chunk > lane ? ct0 : 0, all = ct0;
     for (int c = lane + 64; c < n_chunks; c += 64) {
         const int32_t v = chunk_tot[c];
@@ -282,10 +286,12 @@ __global__ __launch_bounds__(256) void scaled_index_place2_kernel(const ems_roll
     if (k == 0) return;
     float* dst = ro.ent_obs + f * w;
     const int np = k * w;                                                 // k consecutive rows on both sides
+    if (copy) {
 #pragma unroll
-    for (int j = 0; j < PRE; ++j)
-        if (sl + PLACE2_SUB * j < np) dst[sl + PLACE2_SUB * j] = ob[j];
-    for (int x = sl + PLACE2_SUB * PRE; x < np; x += PLACE2_SUB) dst[x] = src[x];
+        for (int j = 0; j < PRE; ++j)
+            if (sl + PLACE2_SUB * j < np) dst[sl + PLACE2_SUB * j] = ob[j];
+        for (int x = sl + PLACE2_SUB * PRE; x < np; x += PLACE2_SUB) dst[x] = src[x];
+    }
     for (int slot = sl; slot < k; slot += PLACE2_SUB) {
         const int dec = slot == sl ? dec0 : pend_decider[b * PCAP + slot];
         const int pos = n_groups > 1 ? goff[wave][dec] + atomicAdd(&cursor[dec * CUR_STRIDE], 1) : rel + slot;
@@ -413,7 +419,7 @@ extern "C" {
 int ems_rollout_index(const ems_rollout* ro, int32_t t, int32_t n_groups, const int32_t* n_pending, const int32_t* pend_decider,
                       const float* pend_obs, void* stream)
 {
-    if (!ro || !n_pending || !pend_decider || !pend_obs) return em::fail(EM_ERR_INVALID, "ems_rollout_index: null argument");
+    if (!ro || !n_pending || !pend_decider) return em::fail(EM_ERR_INVALID, "ems_rollout_index: null argument");
     if (t < 0 || t >= ro->horizon) return em::fail(EM_ERR_INVALID, "ems_rollout_index: step %d outside [0,%d)", t, ro->horizon);
     if (n_groups != 1 && n_groups != ro->n_deciders) return em::fail(EM_ERR_INVALID, "ems_rollout_index: n_groups must be 1 or n_deciders");
     if (ro->n_deciders < 1 || ro->n_deciders > EMS_MAX_DECIDERS) return em::fail(EM_ERR_INVALID, "ems_rollout_index: bad n_deciders");

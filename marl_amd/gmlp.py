@@ -90,8 +90,21 @@ def forward(net: GroupedMLP, x, group_off=None, perm=None, split=1):
 
 
 def policy(net: GroupedMLP, x, ent_env, ent_agent, ent_dst, placement, resource, ent_action, ent_logp, group_off=None,
-           perm=None, split=1, noise=None, explore=True, seed=0, episode=0, rng_step=0, env_offset=0):
+           perm=None, split=1, noise=None, explore=True, seed=0, episode=0, rng_step=0, env_offset=0, x_src=None):
+    """x_src (the environment's pending observation rows, [n_envs][EMS_PENDING_CAP][width]): the rows are read there, at
+    ent_dst, and copied into x on the way (em_gmlp_policy_gather: the step's ems_rollout_index call passed no rows)."""
     st = net.struct()
+    if x_src is not None:
+        assert x_src.is_contiguous() and x_src.shape[-1] == x.shape[1] and x_src.dtype == x.dtype
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().em_gmlp_policy_gather(C.byref(st), net.log_std_ptr(), x_src.data_ptr(), x.data_ptr(), x.shape[1],
+                                                        x.shape[0], _ptr(group_off), _ptr(perm), int(split), _ptr(noise),
+                                                        int(bool(explore)), int(seed) & (2**64 - 1), int(episode), int(rng_step),
+                                                        int(env_offset), ent_env.data_ptr(), ent_agent.data_ptr(),
+                                                        ent_dst.data_ptr(), net.out_dim - 1, ent_action.data_ptr(),
+                                                        ent_logp.data_ptr(), placement.data_ptr(), resource.data_ptr(),
+                                                        _stream(x.device)), "em_gmlp_policy_gather")
+        return
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().em_gmlp_policy(C.byref(st), net.log_std_ptr(), x.data_ptr(), x.shape[1], x.shape[0],
                                              _ptr(group_off), _ptr(perm), int(split), _ptr(noise), int(bool(explore)),

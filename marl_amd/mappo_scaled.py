@@ -79,9 +79,10 @@ class ScaledMAPPO(IPPO):
         # the per-decider grouping of a step serves the central critic's sparse first layer only: deferred, the step is
         # indexed as one group (no histogram, no cursor atomics, identity permutation)
         ng = 1 if defer else D
+        gather = defer and getattr(self, "gather_obs", True)     # as IPPO.record_and_act: the policy launch copies the rows
         with torch.cuda.device(dev):
             _lib.check(self._L.ems_rollout_index(C.byref(ro.struct), t, ng, env.n_pending.data_ptr(), env.pend_decider.data_ptr(),
-                                                 env.pend_obs.data_ptr(), _stream(dev)), "ems_rollout_index")
+                                                 None if gather else env.pend_obs.data_ptr(), _stream(dev)), "ems_rollout_index")
         cc = self.critic.struct()
         B = ro.n_envs
         part = self._partials(ro.capacity_entries)
@@ -100,7 +101,8 @@ class ScaledMAPPO(IPPO):
         # shared actor: the step as one group ({0, entries} sits behind the per-decider offsets), same permutation
         gmlp.policy(self.actor, tt["ent_obs"], tt["ent_env"], tt["ent_agent"], tt["ent_dst"], placement, resource,
                     tt["ent_action"], tt["ent_logp"], tt["group_off"][(D + 1 if ng > 1 else 0):], tt["perm"], self.split, noise=noise, explore=explore,
-                    seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset)
+                    seed=seed, episode=episode, rng_step=t if rng_step is None else rng_step, env_offset=env_offset,
+                    x_src=env.pend_obs if gather else None)
         if defer or not self.overlap_value:
             value()
         ro.steps_recorded = t + 1

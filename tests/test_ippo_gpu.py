@@ -179,3 +179,36 @@ def test_two_launch_index_equals_the_three_launch_path(monkeypatch):
         for g in range(D):
             assert torch.equal(torch.sort(x[8][off[g]:off[g + 1]]).values, torch.sort(y[8][off[g]:off[g + 1]]).values)
     assert ua == ub and torch.equal(aa, ab) and torch.equal(ca, cb)
+
+
+def test_policy_launch_copies_the_observation_rows():
+    """Deferred critic: ems_rollout_index is called without rows and em_gmlp_policy_gather reads each row from the
+    environment's pending list and stores the entry copy itself.  Same storage (rows, actions, log-probs), same environment
+    actions, same parameters after the updates as the index launch's copy + em_gmlp_policy, for independent learners and
+    for the shared actor with the central critic."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 21
+    for algorithm in ("ippo", "mappo"):
+        outs = []
+        for gather in (True, False):
+            tr = IPPOTrainer(cfg, seed=7, device="cuda:0", n_envs=333, algorithm=algorithm, verbose=False)
+            assert tr.algo.defer_values
+            tr.algo.gather_obs = gather
+            rec = []
+            for _ in range(2):
+                st = tr.train_episode(explore=True, record_buffer=True)
+                ro = tr.algo.buffer
+                E, tt = ro.total(), ro.t
+                rec.append((E, st["episode_reward"], tt["ent_obs"][:E].clone(), tt["ent_action"][:E].clone(), tt["ent_logp"][:E].clone(),
+                            tt["ent_dst"][:E].clone()))
+                up = tr.algo.update()
+            outs.append((rec, tr.algo.actor.flat.clone(), tr.algo.critic.flat.clone(), up))
+        (ra, aa, ca, ua), (rb, ab, cb, ub) = outs
+        for x, y in zip(ra, rb):
+            assert x[0] == y[0] and x[0] > 333 and x[1] == y[1]
+            assert bool((x[2] != 0).any())
+            for u, v in zip(x[2:], y[2:]):
+                assert torch.equal(u, v)
+        assert ua == ub and torch.equal(aa, ab) and torch.equal(ca, cb), algorithm
