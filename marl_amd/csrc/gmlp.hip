@@ -159,7 +159,13 @@ __device__ inline void stage_weights(float* lds, const em_gmlp& net, const float
         lds[L::LS + threadIdx.x] = sls;
         // sigma = exp(log_std) of every output, once per workgroup (the same expression, so the same bits as evaluating it
         // per element and tile in the epilogue, where it cost 4 x OT exp() per row)
-        if (sigma) sigma[threadIdx.x] = expf(sls);
+        // behind it: 1 / (2 sigma^2), the log-density's quotient as a product - the expression of the backward kernel's table,
+        // so that the rollout's log-probability and the update's first evaluation of it are the same bits
+        if (sigma) {
+            const float sd = expf(sls);
+            sigma[threadIdx.x] = sd;
+            sigma[16 * OT + threadIdx.x] = 0.5f * (1.0f / (sd * sd));
+        }
     }
 }
 
@@ -437,8 +443,13 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
             float lp = 0.0f, best = -__builtin_inff(), res_raw = 0.0f;
             int best_i = 1 << 20;
             bool all_zero = true;
+            const float* den_f = sd_t + 16 * OT;
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
+                // the lane's four table entries of this output tile in one 16-byte read each, outside the per-element branches
+                const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lds + L::LS + 16 * ot + 4 * q);
+                const f32x4 sd4 = *reinterpret_cast<const f32x4*>(sd_t + 16 * ot + 4 * q);
+                const f32x4 den4 = *reinterpret_cast<const f32x4*>(den_f + 16 * ot + 4 * q);
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
                 if (a.explore && !a.noise) {
                     const uint4 rnd = philox4(a.env_offset + (uint32_t)env, a.episode, a.step,
@@ -453,12 +464,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gmlp_fwd_kernel(const GArgs a)
                     const bool on = o < O;
                     float v = y[ot][r];
                     if (a.explore && on) {
-                        const float ls = lds[L::LS + o];
-                        const float sd = sd_t[o];
                         const float e = a.noise ? (valid ? a.noise[grow * O + o] : 0.0f) : z[r];
-                        v = y[ot][r] + e * sd;                                  // rsample, mappo_algorithm.py:65
+                        v = y[ot][r] + e * sd4[r];                              // rsample, mappo_algorithm.py:65
                         const float d = v - y[ot][r];
-                        lp += -(d * d) / (2.0f * (sd * sd)) - ls - HALF_LOG_2PI;   // Normal.log_prob
+                        lp += -(d * d) * den4[r] - ls4[r] - HALF_LOG_2PI;       // Normal.log_prob (quotient as in the backward kernel)
                     }
                     if (on && valid) a.ent_action[grow * O + o] = v;
                     if (on && o < n) {
@@ -1384,8 +1393,8 @@ int check_gnet(const em_gmlp* net)
 size_t lds_bytes(int ku, int ot, bool bwd, bool stage = false, bool v4 = false)
 {
     const int s1 = v4 ? ku * 16 + 4 : (ku * 16 + 2) | 2, s2 = v4 ? HID + 4 : S2;
-    // forward: + sd table of the policy epilogue (16 ot); backward: + transpose scratch and the two loss tables
-    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * s2 + 16 * ot * s2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 16 * ot) +
+    // forward: + sigma and 1 / (2 sigma^2) tables of the policy epilogue (32 ot); backward: + transpose scratch and the two loss tables
+    return sizeof(float) * ((size_t)HID * s1 + (size_t)HID * s2 + 16 * ot * s2 + 2 * HID + 32 * ot + (bwd ? 4 * HID * TS + 32 * ot : 32 * ot) +
                             (stage ? 4 * 2 * (size_t)((4 * ku * 16 + 63) / 64) * 256 : 0));
 }
 
