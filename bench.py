@@ -347,15 +347,19 @@ def time_env_steps(device, rank, world, B, steps, warmup):
     stream = torch.cuda.current_stream(device)
     sptr = stream.cuda_stream
 
+    # argument tuples converted once: in a 20-launch burst the host's 7-8 us per call, not the GPU's 7, paces the region
+    step_fn = L.em_step
+    call_args = [(h, C.c_void_p(pp), C.c_void_p(rr), None, out, C.c_void_p(sptr)) for pp, rr in ptrs]
+
     def run(k, counter):
+        c = counter[0]
         for _ in range(k):
-            if counter[0] % T == 0:
+            if c % T == 0:
                 env.reset()
-            pp, rr = ptrs[counter[0] % POOL]
-            rc = L.em_step(h, pp, rr, None, out, sptr)
-            if rc:
+            if step_fn(*call_args[c % POOL]):
                 raise RuntimeError(L.em_last_error().decode())
-            counter[0] += 1
+            c += 1
+        counter[0] = c
 
     # Clock warm-up: the driver's default is 5 warmup + 20 timed steps, 175 us in all, which the GPU spends ramping up from its
     # idle clock.  A scratch handle (its own state, same kernel, same batch) runs CLOCK_WARMUP_LAUNCHES steps first; the W warmup
@@ -380,6 +384,11 @@ def time_env_steps(device, rank, world, B, steps, warmup):
         dist.barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the synchronize above parked this thread; a few milliseconds of spinning bring its core back to speed before the clock
+    # starts (without it the first twenty launch calls took 75 us in some runs and 140-180 us in others)
+    t_spin = time.perf_counter() + 0.005
+    while time.perf_counter() < t_spin:
+        pass
     t0 = time.perf_counter()
     ev0.record(stream)
     run(steps, counter)
@@ -494,6 +503,11 @@ def scaled_leg(device, rank, world, B=65536, steps=300):
         dist.barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the synchronize above parked this thread; a few milliseconds of spinning bring its core back to speed before the clock
+    # starts (without it the first twenty launch calls took 75 us in some runs and 140-180 us in others)
+    t_spin = time.perf_counter() + 0.005
+    while time.perf_counter() < t_spin:
+        pass
     t0 = time.perf_counter()
     ev0.record(stream)
     run(steps, counter)
