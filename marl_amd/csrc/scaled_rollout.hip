@@ -5,7 +5,8 @@
 // exclusive scan of the per-environment pending counts; (2) the step's entries are grouped by the network that
 // serves them (decider id for independent learners, one group for a shared network) with a counting sort, which gives
 // the group offsets and the position -> entry permutation the grouped MLP kernels (gmlp.hip) consume; (3) the
-// observation rows are copied into the entry storage.  Two short launches: a chunk-parallel count (scan inside
+// observation rows are copied into the entry storage (or left to the step's em_gmlp_policy_gather launch, which reads them
+// anyway: pend_obs == NULL).  Two short launches: a chunk-parallel count (scan inside
 // 256-environment chunks + histogram) and a wavefront-per-environment placement + copy in which every wavefront redoes
 // the scan of the chunk totals and of the histogram for itself (scaled_index_place2_kernel); above 256 groups, or with
 // EMS_INDEX_THREE_LAUNCHES=1, a single-workgroup scan launch stands between the two.  The order inside a group comes from
