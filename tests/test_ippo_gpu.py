@@ -212,3 +212,33 @@ def test_policy_launch_copies_the_observation_rows():
             for u, v in zip(x[2:], y[2:]):
                 assert torch.equal(u, v)
         assert ua == ub and torch.equal(aa, ab) and torch.equal(ca, cb), algorithm
+
+
+@pytest.mark.parametrize("three", ["0", "1"])
+def test_scaled_storage_overflow_is_reported(monkeypatch, three):
+    """A storage too small for the episode: the step that does not fit records nothing (its counter does not move, its
+    per-environment counts are zero), the sticky flag is set, nothing is written past the capacity, and the trainer raises
+    instead of updating - on the two-launch index path and on the three-launch one."""
+    from marl_amd.ippo import IPPOTrainer
+    from marl_amd.config import SCALED_ENV_CONFIG
+    monkeypatch.setenv("EMS_INDEX_THREE_LAUNCHES", three)
+    cfg = dict(SCALED_ENV_CONFIG)
+    cfg["episode_length"] = 12
+    B, cap = 128, 700                       # ~2.2 entries per environment and step: full after two or three steps
+    tr = IPPOTrainer(cfg, seed=2, device="cuda:0", n_envs=B, algorithm="ippo", capacity_entries=cap, verbose=False)
+    ro = tr.algo.buffer
+    guard = ro.t["ent_env"]                  # [cap] int32: the kernels must not write behind it
+    with pytest.raises(RuntimeError, match="capacity exceeded"):
+        tr.train_episode(explore=True, record_buffer=True)
+        tr.algo.update()
+    assert int(ro.t["err_flag"].item()) & 8
+    c = ro.t["counters"].cpu().tolist()
+    k = ro.t["k_tb"].cpu().numpy().astype(np.int64).sum(axis=1)
+    assert c[0] == 0 and max(c) <= cap and all(b >= a for a, b in zip(c, c[1:]))
+    moved = [b - a for a, b in zip(c, c[1:])]
+    assert [int(v) for v in k] == moved[:len(k)], (list(k), moved)
+    assert 0 in moved[2:] and max(moved) > B
+    E = c[-1]
+    assert bool((guard[:E] >= 0).all()) and bool((guard[:E] < B).all())
+    first = ro.t["first_tb"].cpu().numpy()
+    assert first.max() <= cap
