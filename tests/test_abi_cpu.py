@@ -62,3 +62,25 @@ def test_early_stop_threshold_matches_reference_example():
     # the reference's own worked example: baseline -1200, ratio 0.8 -> -1440 (run_mappo_batch.py:100-103)
     assert rb._early_stop_threshold(-1200) == -1440.0
     assert rb.EVAL_INTERVAL == 50_000 and rb.EVAL_EPISODES == 5 and rb.EARLY_STOP_WINDOW == 3
+
+
+def test_argument_errors_come_back_without_a_gpu():
+    """Every entry point validates before its first HIP call: bad arguments return a negative code and a message
+    (em_last_error) on a machine without a GPU as well."""
+    import ctypes as C
+    from marl_amd import _lib
+    L = _lib.lib()
+    assert L.em_step(None, None, None, None, None, None) < 0
+    assert b"null handle" in L.em_last_error()
+    fake = 0x10000                     # never dereferenced: validation stops the call
+    ro = _lib.EmsRollout(8, 64, 4, 6, 5, 0, *([fake] * 20))
+    assert L.ems_rollout_index(C.byref(ro), 0, 6, None, None, None, None) < 0 and b"null argument" in L.em_last_error()
+    assert L.ems_rollout_index(C.byref(ro), 5, 6, fake, fake, fake, None) < 0 and b"outside" in L.em_last_error()
+    assert L.ems_rollout_index(C.byref(ro), 0, 3, fake, fake, fake, None) < 0 and b"n_groups" in L.em_last_error()
+    assert L.ems_rollout_index(C.byref(ro), 0, 6, fake, fake + 4, None, None) < 0 and b"16-byte aligned" in L.em_last_error()
+    net = _lib.EmGmlp(fake, fake, fake, fake, fake, fake, 0, 68, 64, 65, 2)
+    args = [C.byref(net), fake, fake, None, 68, 16, fake, None, 1, None, 1, 0, 0, 0, 0, fake, fake, fake, 64, fake, fake, fake, fake, None]
+    assert L.em_gmlp_policy_gather(*args) < 0 and b"null argument" in L.em_last_error()      # x_copy missing
+    args[3] = fake
+    args[18] = 10
+    assert L.em_gmlp_policy_gather(*args) < 0 and b"n_place + 1" in L.em_last_error()
